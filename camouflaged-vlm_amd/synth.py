@@ -1,0 +1,105 @@
+"""Deterministic synthetic weights and inputs (no network, no checkpoints, no dataset).
+
+Counter-based: every tensor is drawn from a Philox stream keyed by sha256(name) and the seed, so a
+tensor's values depend only on (name, shape, kind, seed) -- not on construction order, not on
+torch's RNG.  The same tensors are therefore available in this container (loaded into the reference
+by tools/make_golden.py) and on the GPU box (loaded into the HIP path).
+
+Scales follow SURVEY.md §8(d): PyTorch-default-like fan-in scaling for linears/convs, *non-zero*
+rel_pos / pos_embed / conv1_alpha (the reference zero-initialises them, image_encoder.py:78-80,
+485-486; alpha_clip_rw/model.py:878-881), hyper-network tails scaled up so mask logits span
+several units, logit_scale = ln(100).
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from typing import Dict, Iterable, Tuple
+
+import numpy as np
+
+from .spec import ClipGeometry, Entry, SamGeometry, full_entries
+
+
+def _rng(name: str, seed: int) -> np.random.Generator:
+    h = hashlib.sha256(f"{seed}:{name}".encode()).digest()
+    key = np.frombuffer(h[:16], dtype=np.uint64).copy()
+    return np.random.Generator(np.random.Philox(key=key))
+
+
+def _normal(name: str, seed: int, shape: Tuple[int, ...]) -> np.ndarray:
+    return _rng(name, seed).standard_normal(size=shape, dtype=np.float32)
+
+
+def _uniform(name: str, seed: int, shape: Tuple[int, ...]) -> np.ndarray:
+    return _rng(name, seed).random(size=shape, dtype=np.float32) * 2.0 - 1.0
+
+
+def make_tensor(name: str, shape: Tuple[int, ...], kind: str, seed: int = 0) -> np.ndarray:
+    if kind in ("linear", "hyper_tail"):
+        fan_in = shape[1]
+        w = _uniform(name, seed, shape) * (1.0 / math.sqrt(fan_in))
+        # the mask-logit heads are scaled so logits have std of a few units
+        return w * (24.0 if kind == "hyper_tail" else 1.0)
+    if kind == "conv":
+        fan_in = int(np.prod(shape[1:]))
+        return _uniform(name, seed, shape) * (1.0 / math.sqrt(fan_in))
+    if kind == "convT":
+        # ConvTranspose2d weight is (in, out, kh, kw); torch's fan_in uses dim 1
+        fan_in = int(shape[1] * shape[2] * shape[3])
+        return _uniform(name, seed, shape) * (1.0 / math.sqrt(fan_in))
+    if kind == "bias":
+        return _uniform(name, seed, shape) * 0.05
+    if kind == "ln_w":
+        return 1.0 + 0.1 * _normal(name, seed, shape)
+    if kind == "ln_b":
+        return 0.05 * _normal(name, seed, shape)
+    if kind == "relpos":
+        return 0.1 * _normal(name, seed, shape)
+    if kind == "pos":
+        return 0.1 * _normal(name, seed, shape)
+    if kind == "embed":
+        return 0.05 * _normal(name, seed, shape)
+    if kind == "embed_w":
+        return (shape[-1] ** -0.5) * _normal(name, seed, shape)
+    if kind == "proj_w":
+        return (shape[0] ** -0.5) * _normal(name, seed, shape)
+    if kind == "gauss":
+        return _normal(name, seed, shape)
+    if kind == "logit_scale":
+        return np.asarray(math.log(100.0), dtype=np.float32)
+    raise ValueError(f"unknown tensor kind {kind!r} for {name}")
+
+
+def make_state_dict(entries: Iterable[Entry], seed: int = 0) -> Dict[str, np.ndarray]:
+    return {name: np.ascontiguousarray(make_tensor(name, shape, kind, seed), dtype=np.float32)
+            for name, shape, kind in entries}
+
+
+def make_full_state_dict(g: SamGeometry, c: ClipGeometry, seed: int = 0) -> Dict[str, np.ndarray]:
+    return make_state_dict(full_entries(g, c), seed)
+
+
+def make_text_bank(n_cls: int, dim: int, split: str, seed: int = 0) -> np.ndarray:
+    """Unit-norm (n_cls, dim) stand-in for the reference's saved text banks
+    (datasets/ovcamo_info/*CamoPromptsTextFeaturesViTB-14-336.pth: fp32, unit-norm rows)."""
+    t = _normal(f"text_bank.{split}", seed, (n_cls, dim))
+    return (t / np.linalg.norm(t, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def make_inputs(g: SamGeometry, c: ClipGeometry, batch: int, seed: int = 0, index0: int = 0):
+    """Synthetic model inputs, one independent stream per image index so that image i of a batch
+    equals image i generated alone (the reference is batch-size-1 only).
+
+    inp        (B,3,S,S)  ~N(0,1) clipped to +-2.5   (ImageNet-normalised range, demo.py:93-98)
+    clip_image (B,3,R,R)  ~N(0,1)                    (OpenAI-normalised range)
+    clip_mask  (B,1,R,R)  = (1-0.5)/0.26             (alpha_clip.py:88-94 on an all-ones mask)
+    """
+    S, R = g.inp_size, c.image_resolution
+    inp = np.empty((batch, 3, S, S), np.float32)
+    clip_image = np.empty((batch, 3, R, R), np.float32)
+    for b in range(batch):
+        inp[b] = np.clip(_normal(f"input.inp.{index0 + b}", seed, (3, S, S)), -2.5, 2.5)
+        clip_image[b] = _normal(f"input.clip_image.{index0 + b}", seed, (3, R, R))
+    clip_mask = np.full((batch, 1, R, R), (1.0 - 0.5) / 0.26, np.float32)
+    return inp, clip_image, clip_mask

@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE itself on CPU (build container only).
+
+The reference tree (/root/reference) is imported read-only with container-local stubs for the
+third-party packages that are absent here (SURVEY.md §8c recipe); nothing of it is copied.  The
+synthetic weights/inputs come from this repo's own generator (camouflaged_vlm_amd.synth), are loaded
+into the reference modules with ``load_state_dict(strict=True)`` (which is also the check that
+spec.py restates the reference's key layout exactly), and the reference's outputs are saved as
+small ``.npz`` fixtures under tests/golden/.
+
+Usage:  python tools/make_golden.py [--out tests/golden] [--demo-digest]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("CVLM_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+import camouflaged_vlm_amd as cv  # noqa: E402
+from camouflaged_vlm_amd import spec, synth  # noqa: E402
+
+
+def _stub(name: str, **attrs) -> types.ModuleType:
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_reference():
+    """Make ``models.*``, ``cocotrainers.mapleAlphaCLIP`` and ``alpha_clip_rw`` of the reference importable."""
+    _stub("loralib")
+    _stub("dassl")
+    _stub("dassl.engine", TrainerX=object)
+    _stub("dassl.utils", load_checkpoint=None, load_pretrained_weights=None)
+    _stub("dassl.optim", build_optimizer=None, build_lr_scheduler=None)
+    _stub("ftfy", fix_text=lambda s: s)
+    ph = type("P", (), {"__init__": lambda self, *a, **k: None})
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", Compose=ph, Resize=ph, CenterCrop=ph, ToTensor=ph,
+                          Normalize=ph, InterpolationMode=types.SimpleNamespace(BICUBIC=3))
+    _stub("utils", log=lambda *a, **k: None)
+    # parent packages whose __init__ pulls mmcv/open_clip: register bare packages with the right __path__
+    for name, rel in (("models", "models"), ("models.mmseg", "models/mmseg"),
+                      ("models.mmseg.models", "models/mmseg/models")):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, rel)]
+        sys.modules[name] = m
+    sys.path.insert(0, REF)
+    import importlib
+    mm = importlib.import_module("models.models")
+    sys.modules["models"].register = mm.register
+    sys.modules["models"].make = mm.make
+    # bank files were saved from CUDA; the wrapper passes no map_location (sam_maskdecoder_edge.py:177-182)
+    _orig = torch.load
+    torch.load = lambda f, *a, **k: _orig(f, *a, **{**k, "map_location": "cpu", "weights_only": True})
+    importlib.import_module("models.sam_maskdecoder_edge")
+    ml = importlib.import_module("cocotrainers.mapleAlphaCLIP")
+    cm = importlib.import_module("alpha_clip_rw.model")
+    ns = {}
+    with open(os.path.join(REF, "datasets/ovcamo_info/class_names.py")) as f:
+        exec(f.read(), ns)
+    return mm, ml, cm, ns["TRAIN_CLASS_NAMES"], ns["TEST_CLASS_NAMES"]
+
+
+class DotDict:
+    def __init__(self, d):
+        for k, v in d.items():
+            setattr(self, k, DotDict(v) if isinstance(v, dict) else v)
+
+
+def build_reference(mm, ml, cm, g: spec.SamGeometry, c: spec.ClipGeometry, train_names, test_names, seed=0):
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        clip = cm.CLIP(c.embed_dim, c.image_resolution, c.vision_layers, c.vision_width, c.patch_size,
+                       c.context_length, 49408, c.text_width, c.text_heads, c.text_layers,
+                       design_details={"trainer": "MaPLe", "vision_depth": 0, "language_depth": 0,
+                                       "vision_ctx": 0, "language_ctx": 0, "maple_length": c.n_ctx})
+        cfg = DotDict({"MODEL": {"BACKBONE": {"NAME": "ViT-L/14@336px"}},
+                       "TRAINER": {"MAPLE": {"N_CTX": c.n_ctx, "CTX_INIT": "a photo of a", "PREC": "fp32",
+                                             "PROMPT_DEPTH": c.prompt_depth}},
+                       "INPUT": {"SIZE": [c.image_resolution, c.image_resolution]}})
+        custom = ml.CustomCLIP(cfg, train_names[:c.n_cls_train], test_names[:c.n_cls_test], clip.float())
+        enc = dict(name="sam", img_size=g.inp_size, mlp_ratio=g.mlp_ratio, patch_size=g.patch_size,
+                   qkv_bias=True, use_rel_pos=True, window_size=g.window_size, out_chans=g.out_chans,
+                   scale_factor=32, input_type="fft", freq_nums=0.25, prompt_type="highpass",
+                   prompt_embed_dim=g.prompt_embed_dim, tuning_stage=1234, handcrafted_tune=True,
+                   embedding_tune=True, adaptor="adaptor", embed_dim=g.embed_dim, depth=g.depth,
+                   num_heads=g.num_heads, global_attn_indexes=list(g.global_attn_indexes))
+        model = mm.make({"name": "sam_maskdecoder_edge", "args": {"inp_size": g.inp_size, "loss": "iou",
+                                                                 "encoder_mode": enc}})
+        model.device = torch.device("cpu")
+        # use the first n rows of the reference's real banks
+        model.train_text_features = model.train_text_features[:c.n_cls_train].float()
+        model.test_text_features = model.test_text_features[:c.n_cls_test].float()
+        model.load_mapleAlphaCLIP(custom)
+    finally:
+        os.chdir(cwd)
+    sd = synth.make_full_state_dict(g, c, seed)
+    ref_keys = set(model.state_dict().keys())
+    assert ref_keys == set(sd.keys()), (sorted(ref_keys - set(sd))[:8], sorted(set(sd) - ref_keys)[:8])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    eot_test = custom.tokenized_prompts_test.argmax(dim=-1).numpy().astype(np.int32)
+    eot_train = custom.tokenized_prompts.argmax(dim=-1).numpy().astype(np.int32)
+    return model, sd, eot_train, eot_test
+
+
+def run_reference(model, inp, clip_image, clip_mask, R):
+    """demo.py:110-122, one image at a time (the reference is B=1 only)."""
+    import torch.nn.functional as F
+    masks, preds, logits, l1 = [], [], [], []
+    with torch.no_grad():
+        for b in range(inp.shape[0]):
+            i, ci, cm_ = (torch.from_numpy(t[b:b + 1]) for t in (inp, clip_image, clip_mask))
+            m = model.infer_test(i, ci, cm_)
+            _, _, _, s1 = model.clip_model(ci, cm_, train=False)
+            alpha = F.interpolate(torch.sigmoid(m), (R, R), mode="bilinear", align_corners=False)
+            _, _, p, s = model.clip_model(ci, alpha, train=False)
+            masks.append(m.numpy()); preds.append(p.numpy()); logits.append(s.numpy()); l1.append(s1.numpy())
+    return np.concatenate(masks), np.concatenate(preds), np.concatenate(logits), np.concatenate(l1)
+
+
+def tiny(out_dir, mods):
+    mm, ml, cm, train_names, test_names = mods
+    g, c = spec.TINY_SAM, spec.TINY_CLIP
+    model, sd, eot_train, eot_test = build_reference(mm, ml, cm, g, c, train_names, test_names)
+    inp, clip_image, clip_mask = synth.make_inputs(g, c, batch=2)
+    taps = {}
+    hooks = []
+
+    def tap(name, mod, fn=lambda o: o):
+        def hook(m, i, o):
+            if name not in taps:            # first image only
+                taps[name] = fn(o).detach().numpy().copy()
+        hooks.append(mod.register_forward_hook(hook))
+
+    enc = model.image_encoder
+    tap("patch_embed", enc.patch_embed)
+    for i, blk in enumerate(enc.blocks):
+        tap(f"block{i}", blk)
+    tap("attn0", enc.blocks[0].attn)           # windowed attention incl. pad rows (4 windows x 14 x 14)
+    tap("attn1", enc.blocks[1].attn)           # global attention
+    tap("features", enc, lambda o: o[0])
+    tap("upscaled", model.mask_decoder.output_upscaling)
+    tap("edge_features", model.mask_decoder.embedding_encoder)
+    tap("hs", model.mask_decoder.transformer, lambda o: o[0])
+    tap("src", model.mask_decoder.transformer, lambda o: o[1])
+    tap("low_res_masks", model.mask_decoder, lambda o: o[0])
+    tap("clip_visual", model.clip_model.image_encoder)
+    tap("clip_text", model.clip_model.text_encoder)
+    with torch.no_grad():
+        hp = enc.prompt_generator.fft(torch.from_numpy(inp[:1]), 0.25).numpy()
+        pe = model.get_dense_pe().numpy()
+    masks, preds, logits, logits1 = run_reference(model, inp, clip_image, clip_mask, c.image_resolution)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(
+        os.path.join(out_dir, "tiny_cascade.npz"),
+        mask_logits=masks.astype(np.float32), pred=preds.astype(np.int64), class_logits=logits.astype(np.float32),
+        pass1_logits=logits1.astype(np.float32), eot_train=eot_train, eot_test=eot_test,
+        bank_test=model.test_text_features.numpy(), bank_train=model.train_text_features.numpy(),
+        highpass=hp.astype(np.float32), dense_pe=pe.astype(np.float32),
+        **{"tap_" + k: v.astype(np.float32) for k, v in taps.items()})
+    print("tiny: mask std %.3f min %.3f max %.3f | pred %s | logits[0,:3] %s" %
+          (masks.std(), masks.min(), masks.max(), preds, logits[0, :3]))
+    frac = float((np.abs(masks) < 1e-3).mean())
+    print("tiny: frac |logit|<1e-3 = %.2e ; positive frac %.3f" % (frac, float((masks > 0).mean())))
+
+
+def tokens(out_dir, mods):
+    """G4 constants: tokenised OVCamo prompts (mapleAlphaCLIP.py:132-168) and the real text banks."""
+    mm, ml, cm, train_names, test_names = mods
+    import importlib
+    ac = importlib.import_module("alpha_clip_rw.alpha_clip")
+    fmt = lambda names: ["a photo of a " + n.replace("_", " ") + "." for n in names]
+    tk_train = torch.cat([ac.tokenize(p) for p in fmt(train_names)]).numpy().astype(np.int32)
+    tk_test = torch.cat([ac.tokenize(p) for p in fmt(test_names)]).numpy().astype(np.int32)
+    banks = {}
+    for split in ("Train", "Test"):
+        banks[split.lower()] = torch.load(
+            os.path.join(REF, f"datasets/ovcamo_info/{split}CamoPromptsTextFeaturesViTB-14-336.pth")).float().numpy()
+    np.savez_compressed(os.path.join(out_dir, "ovcamo_constants.npz"), tokens_train=tk_train, tokens_test=tk_test,
+                        bank_train=banks["train"], bank_test=banks["test"],
+                        names_train=np.array(train_names), names_test=np.array(test_names))
+    print("tokens:", tk_train.shape, tk_test.shape, "eot test", tk_test.argmax(-1)[:8])
+
+
+def demo_digest(out_dir, mods, n_images=1):
+    """G3: full demo.yaml geometry, B=1, digests only (per-stage stats + packed mask + logits)."""
+    mm, ml, cm, train_names, test_names = mods
+    g, c = spec.DEMO_SAM, spec.DEMO_CLIP
+    model, sd, eot_train, eot_test = build_reference(mm, ml, cm, g, c, train_names, test_names)
+    inp, clip_image, clip_mask = synth.make_inputs(g, c, batch=n_images)
+    import time
+    t0 = time.time()
+    masks, preds, logits, logits1 = run_reference(model, inp, clip_image, clip_mask, c.image_resolution)
+    dt = time.time() - t0
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, masks[0].size, size=4096)
+    np.savez_compressed(
+        os.path.join(out_dir, "demo_digest.npz"),
+        mask_bits=np.packbits(masks > 0), mask_samples=masks.reshape(n_images, -1)[:, idx], sample_idx=idx,
+        mask_stats=np.array([masks.mean(), masks.std(), masks.min(), masks.max()], np.float64),
+        pred=preds.astype(np.int64), class_logits=logits.astype(np.float32), pass1_logits=logits1.astype(np.float32),
+        eot_test=eot_test, eot_train=eot_train, ref_seconds=np.array(dt), threads=np.array(torch.get_num_threads()))
+    print("demo: %d image(s) in %.1f s; mask std %.3f; pred %s" % (n_images, dt, masks.std(), preds))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--demo-digest", action="store_true")
+    ap.add_argument("--skip-tiny", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    mods = install_reference()
+    tokens(args.out, mods)
+    if not args.skip_tiny:
+        tiny(args.out, mods)
+    if args.demo_digest:
+        demo_digest(args.out, mods)
