@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the camouflaged-vlm hot path.
+//
+// Number formats used between kernels
+//   f32  : plain float tensors (residual streams, final outputs)
+//   h2   : "split half" -- a value v is carried as two fp16 planes  hi = fp16(v), lo = fp16(v - hi)
+//          (~22 significand bits).  MFMA products are formed as hi*hi + lo*hi + hi*lo with fp32
+//          accumulation, which keeps the 1e-3 parity budget of the fp32 reference while running on
+//          the fp16 matrix pipe (gfx950 has no xf32/TF32, and fp32 MFMA is 1/16 of the fp16 rate).
+//          split == 1 ("fast") uses the hi plane only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define CVLM_WAVE 64
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// 16-byte asynchronous global -> LDS copy (LDS destination = wave-uniform base + lane*16).
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gptr, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split_h2(float v, half_t& hi, half_t& lo) {
+    // Pin v in a register first: with fp contraction hipcc otherwise re-derives `hi` for the `lo`
+    // computation with v_fma_mixlo_f16 (product rounded once) while the stored hi comes from the
+    // rounded product -- on near-ties the two differ by one fp16 ulp and hi + lo is off by that ulp.
+    asm volatile("" : "+v"(v));
+    hi = (half_t)v;
+    lo = (half_t)(v - (float)hi);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activation codes shared by the GEMM epilogue and the row kernels
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_ABS_POST = 4 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact-erf GELU
+        case ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));                   // x*sigmoid(1.702x)
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        default: return v;
+    }
+}
+
+#define CVLM_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

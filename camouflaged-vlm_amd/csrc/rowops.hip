@@ -1,0 +1,603 @@
+// HBM-bound row / gather kernels of the path (LayerNorm, broadcasts, patch gathers, im2col, ...).
+// All arithmetic fp32; outputs optionally emitted as split-half (h2) planes for the MFMA GEMMs.
+// Loads/stores are 16-byte (float4) / 8-byte (half4) vectors, one wave per row for reductions.
+#include "common.h"
+#include "../../include/cvlm.h"
+
+namespace {
+
+__device__ __forceinline__ void store_h2x4(half_t* hi, half_t* lo, int64_t off, const float v[4]) {
+    half_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_h2(v[j], h[j], l[j]);
+    *(half4*)(hi + off) = half4{h[0], h[1], h[2], h[3]};
+    if (lo) *(half4*)(lo + off) = half4{l[0], l[1], l[2], l[3]};
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row kept in registers (D <= 2048, D % 4 == 0)
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ add, int add_rows,
+                                                        float* __restrict__ sum_out,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, int act,
+                                                        float* __restrict__ out_f32, half_t* __restrict__ out_hi,
+                                                        half_t* __restrict__ out_lo, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    float4 v[LN_MAXV];
+    const float4* xr = (const float4*)(x + (int64_t)row * ldx);
+    const float4* ar = add ? (const float4*)(add + (int64_t)(row % add_rows) * D) : nullptr;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            float4 t = xr[c];
+            if (ar) { const float4 a = ar[c]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+            v[i] = t;
+            s += (t.x + t.y) + (t.z + t.w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    if (sum_out) {
+        float4* so = (float4*)(sum_out + (int64_t)row * D);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) { const int c = lane + i * 64; if (c < nv) so[c] = v[i]; }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const float4* gr = (const float4*)gamma;
+    const float4* br = (const float4*)beta;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 g = gr[c], b = br[c];
+            float o[4];
+            o[0] = (v[i].x - mean) * rstd * g.x + b.x;
+            o[1] = (v[i].y - mean) * rstd * g.y + b.y;
+            o[2] = (v[i].z - mean) * rstd * g.z + b.z;
+            o[3] = (v[i].w - mean) * rstd * g.w + b.w;
+            if (act != ACT_NONE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = apply_act(o[j], act);
+            }
+            const int64_t off = (int64_t)row * D + c * 4;
+            if (out_f32) *(float4*)(out_f32 + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (out_hi) store_h2x4(out_hi, out_lo, off, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       int b_rows, float scale, float* __restrict__ out_f32,
+                                                       half_t* __restrict__ out_hi, half_t* __restrict__ out_lo,
+                                                       int64_t nvec, int dv) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / dv;
+        const int c = (int)(i - row * dv);
+        float4 t = ((const float4*)a)[i];
+        if (b) {
+            const float4 u = ((const float4*)b)[(row % b_rows) * dv + c];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        float o[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
+        if (out_f32) ((float4*)out_f32)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (out_hi) store_h2x4(out_hi, out_lo, i * 4, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ s0, int C0,
+                                                       const float* __restrict__ s1, int C1, int B, int H, int W,
+                                                       int p, half_t* __restrict__ out_hi,
+                                                       half_t* __restrict__ out_lo, int ldk) {
+    const int gh = H / p, gw = W / p;
+    const int kg = ldk >> 3;                                       // groups of 8 columns
+    const int64_t total = (int64_t)B * gh * gw * kg;
+    const int K = (C0 + C1) * p * p;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / kg;
+        const int k0 = (int)(i - m * kg) * 8;
+        const int px = (int)(m % gw);
+        const int py = (int)((m / gw) % gh);
+        const int b = (int)(m / ((int64_t)gw * gh));
+        half_t hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            float v = 0.f;
+            if (k < K) {
+                const int c = k / (p * p), r = k - c * p * p;
+                const int iy = r / p, ix = r - iy * p;
+                const float* src = c < C0 ? s0 + ((int64_t)(b * C0 + c) * H) * W
+                                          : s1 + ((int64_t)(b * C1 + (c - C0)) * H) * W;
+                v = src[(int64_t)(py * p + iy) * W + px * p + ix];
+            }
+            split_h2(v, hi[j], lo[j]);
+        }
+        *(half8*)(out_hi + m * ldk + k0) = half8{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        if (out_lo) *(half8*)(out_lo + m * ldk + k0) = half8{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+    }
+}
+
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int B, int H, int W, int C,
+                                                        half_t* __restrict__ out_hi, half_t* __restrict__ out_lo) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)B * H * W * 9 * cg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cg) * 8;
+        const int tap = (int)((i / cg) % 9);
+        const int64_t m = i / ((int64_t)cg * 9);
+        const int xx = (int)(m % W), yy = (int)((m / W) % H);
+        const int b = (int)(m / ((int64_t)W * H));
+        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            const float4* src = (const float4*)(x + (((int64_t)b * H + sy) * W + sx) * C + c0);
+            const float4 a = src[0], d = src[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = d.x; v[5] = d.y; v[6] = d.z; v[7] = d.w;
+        }
+        half_t hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split_h2(v[j], hi[j], lo[j]);
+        const int64_t off = m * (9 * C) + tap * C + c0;
+        *(half8*)(out_hi + off) = half8{hi[0], hi[1], hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+        if (out_lo) *(half8*)(out_lo + off) = half8{lo[0], lo[1], lo[2], lo[3], lo[4], lo[5], lo[6], lo[7]};
+    }
+}
+
+// out[b][t][c] = xflat[b][c*T + t]: transpose of the (D x T) re-read of each image's token matrix
+__global__ __launch_bounds__(256) void reinterpret_transpose_kernel(const float* __restrict__ x, int T, int D,
+                                                                    half_t* __restrict__ out_hi,
+                                                                    half_t* __restrict__ out_lo) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const float* xb = x + (int64_t)b * T * D;
+    for (int r = ty; r < 32; r += 8) {                                 // read Y[c0+r][t0+tx]
+        const int c = c0 + r, t = t0 + tx;
+        tile[r][tx] = (c < D && t < T) ? xb[(int64_t)c * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {                                 // write out[t0+r][c0+tx]
+        const int t = t0 + r, c = c0 + tx;
+        if (t < T && c < D) {
+            half_t h, l;
+            split_h2(tile[tx][r], h, l);
+            const int64_t off = ((int64_t)b * T + t) * D + c;
+            out_hi[off] = h;
+            if (out_lo) out_lo[off] = l;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, half_t* __restrict__ hi,
+                                                    half_t* __restrict__ lo, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 t = ((const float4*)x)[i];
+        const float o[4] = {t.x, t.y, t.z, t.w};
+        store_h2x4(hi, lo, i * 4, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_pe_kernel(const float* __restrict__ gauss, int size, int C,
+                                                       float* __restrict__ out) {
+    const int half = C >> 1;
+    const int64_t total = (int64_t)size * size * half;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % half);
+        const int t = (int)(i / half);
+        const int xx = t % size, yy = t / size;
+        const float cx = 2.0f * (((float)xx + 0.5f) / (float)size) - 1.0f;
+        const float cy = 2.0f * (((float)yy + 0.5f) / (float)size) - 1.0f;
+        float v = cx * gauss[c] + cy * gauss[half + c];
+        v = 6.283185307179586f * v;
+        out[(int64_t)t * C + c] = sinf(v);
+        out[(int64_t)t * C + half + c] = cosf(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict__ up, const float* __restrict__ edge,
+                                                        const float* __restrict__ hyper, int HW, int C,
+                                                        float* __restrict__ low) {
+    const int b = blockIdx.y;
+    const float* h0 = hyper + (int64_t)b * 5 * C;
+    const float* h4 = h0 + 4 * C;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < HW; pix += gridDim.x * blockDim.x) {
+        const float4* u = (const float4*)(up + ((int64_t)b * HW + pix) * C);
+        const float4* e = (const float4*)(edge + ((int64_t)b * HW + pix) * C);
+        float m = 0.f, g = 0.f;
+        for (int c = 0; c < (C >> 2); ++c) {
+            const float4 a = u[c], d = e[c];
+            const float4 w0 = ((const float4*)h0)[c], w4 = ((const float4*)h4)[c];
+            m += a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w;
+            g += d.x * w4.x + d.y * w4.y + d.z * w4.z + d.w * w4.w;
+        }
+        const float s = 1.0f / (1.0f + expf(-g));
+        low[(int64_t)b * HW + pix] = m * s + m;
+    }
+}
+
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ in, int hin, int win,
+                                                       float* __restrict__ out, int hout, int wout, int sigmoid_in,
+                                                       int64_t total) {
+    const float sy = (float)hin / (float)hout, sx = (float)win / (float)wout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wout), oy = (int)((i / wout) % hout);
+        const int64_t n = i / ((int64_t)wout * hout);
+        float fy = sy * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        float fx = sx * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < hin - 1 ? 1 : 0), x1 = x0 + (x0 < win - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = in + n * (int64_t)hin * win;
+        float v00 = p[(int64_t)y0 * win + x0], v01 = p[(int64_t)y0 * win + x1];
+        float v10 = p[(int64_t)y1 * win + x0], v11 = p[(int64_t)y1 * win + x1];
+        if (sigmoid_in) {
+            v00 = 1.0f / (1.0f + expf(-v00)); v01 = 1.0f / (1.0f + expf(-v01));
+            v10 = 1.0f / (1.0f + expf(-v10)); v11 = 1.0f / (1.0f + expf(-v11));
+        }
+        out[i] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_assemble_kernel(const float* __restrict__ patches,
+                                                            const float* __restrict__ cls,
+                                                            const float* __restrict__ pos,
+                                                            const float* __restrict__ ctx, int P, int Wd, int nctx,
+                                                            float* __restrict__ out, int64_t total) {
+    const int L = 1 + P + nctx, wv = Wd >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % wv);
+        const int t = (int)((i / wv) % L);
+        const int64_t b = i / ((int64_t)wv * L);
+        float4 v;
+        if (t == 0) {
+            const float4 a = ((const float4*)cls)[c], q = ((const float4*)pos)[c];
+            v = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+        } else if (t <= P) {
+            const float4 a = ((const float4*)patches)[(b * P + (t - 1)) * wv + c];
+            const float4 q = ((const float4*)pos)[(int64_t)t * wv + c];
+            v = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+        } else {
+            v = ((const float4*)ctx)[(int64_t)(t - 1 - P) * wv + c];
+        }
+        ((float4*)out)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void overwrite_rows_kernel(float* __restrict__ x, int L, int Wd, int first, int n,
+                                                             const float* __restrict__ src, int64_t total) {
+    const int wv = Wd >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % wv);
+        const int r = (int)((i / wv) % n);
+        const int64_t b = i / ((int64_t)wv * n);
+        ((float4*)x)[(b * L + first + r) * wv + c] = ((const float4*)src)[(int64_t)r * wv + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, int L, int Wd,
+                                                          const int32_t* __restrict__ idx, int fixed,
+                                                          float* __restrict__ out, int64_t total) {
+    const int wv = Wd >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % wv);
+        const int64_t b = i / wv;
+        const int r = idx ? idx[b] : fixed;
+        ((float4*)out)[i] = ((const float4*)x)[(b * L + r) * wv + c];
+    }
+}
+
+// one 256-thread block per image
+__global__ __launch_bounds__(256) void clip_head_kernel(const float* __restrict__ img, const float* __restrict__ txt,
+                                                        float lscale, int C, int D, float* __restrict__ img_n,
+                                                        float* __restrict__ logits, int64_t* __restrict__ pred,
+                                                        float* __restrict__ txt_sel) {
+    __shared__ float red[4];
+    __shared__ float slog[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* x = img + (int64_t)b * D;
+    float s = 0.f;
+    for (int d = tid; d < D; d += 256) s += x[d] * x[d];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    for (int d = tid; d < D; d += 256) img_n[(int64_t)b * D + d] = x[d] / nrm;
+    for (int c = wave; c < C; c += 4) {
+        const float* t = txt + (int64_t)c * D;
+        float a = 0.f;
+        for (int d = lane; d < D; d += 64) a += (lscale * (x[d] / nrm)) * t[d];
+        a = wave_sum(a);
+        if (lane == 0) { slog[c] = a; logits[(int64_t)b * C + c] = a; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0; float bv = slog[0];
+        for (int c = 1; c < C; ++c) if (slog[c] > bv) { bv = slog[c]; best = c; }
+        pred[b] = best;
+        red[0] = __int_as_float(best);
+    }
+    __syncthreads();
+    const int best = __float_as_int(red[0]);
+    for (int d = tid; d < D; d += 256) txt_sel[(int64_t)b * D + d] = txt[(int64_t)best * D + d];
+}
+
+__global__ __launch_bounds__(64) void normalize_add_kernel(const float* __restrict__ x, const float* __restrict__ add,
+                                                           int D, float* __restrict__ out) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const float* xr = x + (int64_t)r * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += xr[d] * xr[d];
+    const float nrm = sqrtf(wave_sum(s));
+    for (int d = lane; d < D; d += 64) out[(int64_t)r * D + d] = xr[d] / nrm + (add ? add[(int64_t)r * D + d] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small fp32 attention (two-way decoder).  hd <= 32.
+// ------------------------------------------------------------------------------------------------
+constexpr int SA_MAXHD = 32;
+
+// few keys: one thread per (b, q, h)
+__global__ __launch_bounds__(256) void small_attn_thread_kernel(const float* __restrict__ q, int64_t ldq,
+                                                                const float* __restrict__ k, int64_t ldk,
+                                                                const float* __restrict__ v, int64_t ldv,
+                                                                float* __restrict__ out, int64_t ldo, int nq, int nk,
+                                                                int heads, int hd, int64_t total) {
+    const float sc = 1.0f / sqrtf((float)hd);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int h = (int)(i % heads);
+        const int qi = (int)((i / heads) % nq);
+        const int64_t b = i / ((int64_t)heads * nq);
+        const float* qp = q + (b * nq + qi) * ldq + h * hd;
+        float qr[SA_MAXHD], acc[SA_MAXHD];
+#pragma unroll
+        for (int d = 0; d < SA_MAXHD; ++d) { qr[d] = d < hd ? qp[d] : 0.f; acc[d] = 0.f; }
+        float mx = -INFINITY, l = 0.f;
+        for (int j = 0; j < nk; ++j) {
+            const float* kp = k + (b * nk + j) * ldk + h * hd;
+            const float* vp = v + (b * nk + j) * ldv + h * hd;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) s += qr[d] * kp[d];
+            s *= sc;
+            const float mn = fmaxf(mx, s);
+            const float f = expf(mx - mn), pj = expf(s - mn);
+            l = l * f + pj;
+#pragma unroll
+            for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) acc[d] = acc[d] * f + pj * vp[d];
+            mx = mn;
+        }
+        float* op = out + (b * nq + qi) * ldo + h * hd;
+#pragma unroll
+        for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) op[d] = acc[d] / l;
+    }
+}
+
+// many keys: one wave per (b, q, h), lanes stride over keys
+__global__ __launch_bounds__(256) void small_attn_wave_kernel(const float* __restrict__ q, int64_t ldq,
+                                                              const float* __restrict__ k, int64_t ldk,
+                                                              const float* __restrict__ v, int64_t ldv,
+                                                              float* __restrict__ out, int64_t ldo, int nq, int nk,
+                                                              int heads, int hd, int64_t total) {
+    const float sc = 1.0f / sqrtf((float)hd);
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= total) return;
+    const int h = (int)(i % heads);
+    const int qi = (int)((i / heads) % nq);
+    const int64_t b = i / ((int64_t)heads * nq);
+    const float* qp = q + (b * nq + qi) * ldq + h * hd;
+    float qr[SA_MAXHD], acc[SA_MAXHD];
+#pragma unroll
+    for (int d = 0; d < SA_MAXHD; ++d) { qr[d] = d < hd ? qp[d] : 0.f; acc[d] = 0.f; }
+    float mx = -INFINITY, l = 0.f;
+    for (int j = lane; j < nk; j += 64) {
+        const float* kp = k + (b * nk + j) * ldk + h * hd;
+        const float* vp = v + (b * nk + j) * ldv + h * hd;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) s += qr[d] * kp[d];
+        s *= sc;
+        const float mn = fmaxf(mx, s);
+        const float f = expf(mx - mn), pj = expf(s - mn);
+        l = l * f + pj;
+#pragma unroll
+        for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) acc[d] = acc[d] * f + pj * vp[d];
+        mx = mn;
+    }
+    const float M = wave_max(mx);
+    const float f = (mx == -INFINITY) ? 0.f : expf(mx - M);
+    l = wave_sum(l * f);
+    float* op = out + (b * nq + qi) * ldo + h * hd;
+#pragma unroll
+    for (int d = 0; d < SA_MAXHD; ++d) {
+        if (d < hd) {
+            const float a = wave_sum(acc[d] * f);
+            if (lane == 0) op[d] = a / l;
+        }
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 8192) {
+    int64_t g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cvlm_layernorm(const float* x, int64_t ldx, const float* add, int32_t add_rows, float* sum_out,
+                   const float* gamma, const float* beta, float eps, int32_t act, float* out_f32, void* out_hi,
+                   void* out_lo, int32_t M, int32_t D, void* stream) {
+    if (!x || !gamma || !beta || M <= 0 || D <= 0 || (D & 3) || D > LN_MAXV * 256 || (ldx & 3)) return CVLM_E_BADARG;
+    if (add && add_rows <= 0) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, add, add_rows,
+                       sum_out, gamma, beta, eps, act, out_f32, (half_t*)out_hi, (half_t*)out_lo, M, D);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, float* out_f32, void* out_hi,
+                  void* out_lo, int32_t M, int32_t D, void* stream) {
+    if (!a || M <= 0 || D <= 0 || (D & 3) || (b && b_rows <= 0)) return CVLM_E_BADARG;
+    const int64_t nvec = (int64_t)M * (D >> 2);
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, a, b, b_rows, scale,
+                       out_f32, (half_t*)out_hi, (half_t*)out_lo, nvec, D >> 2);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_split_f32(const float* x, void* out_hi, void* out_lo, int64_t n, void* stream) {
+    if (!x || !out_hi || n <= 0 || (n & 3)) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(split_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, (hipStream_t)stream, x, (half_t*)out_hi,
+                       (half_t*)out_lo, n >> 2);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_patchify(const float* src0, int32_t C0, const float* src1, int32_t C1, int32_t B, int32_t H, int32_t W,
+                  int32_t p, void* out_hi, void* out_lo, int32_t ldk, void* stream) {
+    if (!src0 || !out_hi || p <= 0 || (H % p) || (W % p) || (ldk & 7) || ldk < (C0 + C1) * p * p) return CVLM_E_BADARG;
+    if (C1 > 0 && !src1) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)B * (H / p) * (W / p) * (ldk >> 3);
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src0, C0, src1, C1,
+                       B, H, W, p, (half_t*)out_hi, (half_t*)out_lo, ldk);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, void* out_hi, void* out_lo,
+                   void* stream) {
+    if (!x || !out_hi || (C & 7)) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)B * H * W * 9 * (C >> 3);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, B, H,
+                       W, C, (half_t*)out_hi, (half_t*)out_lo);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, void* out_hi, void* out_lo,
+                               void* stream) {
+    if (!x || !out_hi || B <= 0 || T <= 0 || D <= 0) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(reinterpret_transpose_kernel, dim3((T + 31) / 32, (D + 31) / 32, B), dim3(256), 0,
+                       (hipStream_t)stream, x, T, D, (half_t*)out_hi, (half_t*)out_lo);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_dense_pe(const float* gauss, int32_t size, int32_t C, float* out, void* stream) {
+    if (!gauss || !out || size <= 0 || (C & 1)) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(dense_pe_kernel, dim3(grid_for((int64_t)size * size * (C >> 1))), dim3(256), 0,
+                       (hipStream_t)stream, gauss, size, C, out);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_mask_head(const float* up, const float* edge_emb, const float* hyper, int32_t B, int32_t HW, int32_t C,
+                   float* low, void* stream) {
+    if (!up || !edge_emb || !hyper || !low || (C & 3)) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(mask_head_kernel, dim3(grid_for(HW, 256, 1024), B), dim3(256), 0, (hipStream_t)stream, up,
+                       edge_emb, hyper, HW, C, low);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_bilinear(const float* in, int32_t N, int32_t hin, int32_t win, float* out, int32_t hout, int32_t wout,
+                  int32_t sigmoid_in, void* stream) {
+    if (!in || !out || N <= 0) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)N * hout * wout;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, hin, win, out,
+                       hout, wout, sigmoid_in, total);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_clip_assemble(const float* patches, const float* cls, const float* pos, const float* ctx, int32_t B,
+                       int32_t P, int32_t W, int32_t nctx, float* out, void* stream) {
+    if (!patches || !cls || !pos || !ctx || !out || (W & 3)) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)B * (1 + P + nctx) * (W >> 2);
+    hipLaunchKernelGGL(clip_assemble_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, patches, cls,
+                       pos, ctx, P, W, nctx, out, total);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_overwrite_rows(float* x, int32_t B, int32_t L, int32_t W, int32_t first, int32_t n, const float* src,
+                        void* stream) {
+    if (!x || !src || (W & 3) || first < 0 || first + n > L) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)B * n * (W >> 2);
+    hipLaunchKernelGGL(overwrite_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, L, W, first,
+                       n, src, total);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_gather_rows(const float* x, int32_t B, int32_t L, int32_t W, const int32_t* idx, int32_t fixed, float* out,
+                     void* stream) {
+    if (!x || !out || (W & 3)) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)B * (W >> 2);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, L, W, idx,
+                       fixed, out, total);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_clip_head(const float* img, const float* txt, float logit_scale_exp, int32_t B, int32_t C, int32_t D,
+                   float* img_n, float* logits, int64_t* pred, float* txt_sel, void* stream) {
+    if (!img || !txt || !img_n || !logits || !pred || !txt_sel || C <= 0 || C > 1024) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(clip_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, img, txt, logit_scale_exp, C, D,
+                       img_n, logits, pred, txt_sel);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_normalize_add(const float* x, const float* add, int32_t R, int32_t D, float* out, void* stream) {
+    if (!x || !out || R <= 0) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(normalize_add_kernel, dim3(R), dim3(64), 0, (hipStream_t)stream, x, add, D, out);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_small_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                         float* out, int64_t ldo, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
+                         void* stream) {
+    if (!q || !k || !v || !out || hd <= 0 || hd > SA_MAXHD || nk <= 0 || nq <= 0) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)B * nq * heads;
+    if (nk <= 64) {
+        hipLaunchKernelGGL(small_attn_thread_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, q, ldq,
+                           k, ldk, v, ldv, out, ldo, nq, nk, heads, hd, total);
+    } else {
+        hipLaunchKernelGGL(small_attn_wave_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, nq, nk, heads, hd, total);
+    }
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_abi_version(void) { return CVLM_ABI_VERSION; }
+const char* cvlm_target_arch(void) { return "gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,271 @@
+"""ctypes binding of libcvlm_hip.so (include/cvlm.h) -- the only way compute happens in this package.
+
+There is no CPU fallback: if the shared library is missing or a launch fails, a RuntimeError is
+raised.  torch is used for device memory and streams only (tensors' ``data_ptr()`` are handed to the
+C ABI together with the current HIP stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libcvlm_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_QUICKGELU, ACT_RELU, ACT_ABS_POST = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "cvlm_abi_version", "cvlm_target_arch", "cvlm_gemm", "cvlm_layernorm", "cvlm_add_rows", "cvlm_split_f32",
+    "cvlm_patchify", "cvlm_im2col3x3", "cvlm_reinterpret_transpose", "cvlm_attention", "cvlm_small_attention",
+    "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
+    "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add",
+]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a_hi", C.c_void_p), ("a_lo", C.c_void_p), ("lda", C.c_int64), ("stride_a", C.c_int64),
+        ("w_hi", C.c_void_p), ("w_lo", C.c_void_p), ("ldw", C.c_int64), ("stride_w", C.c_int64),
+        ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_int64), ("stride_r", C.c_int64),
+        ("out_f32", C.c_void_p), ("ldo", C.c_int64), ("stride_o", C.c_int64),
+        ("out_hi", C.c_void_p), ("out_lo", C.c_void_p), ("ldoh", C.c_int64), ("stride_oh", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+        ("alpha", C.c_float), ("act", C.c_int32), ("split", C.c_int32),
+        ("ps_h", C.c_int32), ("ps_w", C.c_int32), ("ps_c2", C.c_int32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("qkv_hi", C.c_void_p), ("qkv_lo", C.c_void_p), ("pad_hi", C.c_void_p), ("pad_lo", C.c_void_p),
+        ("relh_hi", C.c_void_p), ("relh_lo", C.c_void_p), ("relw_hi", C.c_void_p), ("relw_lo", C.c_void_p),
+        ("out_hi", C.c_void_p), ("out_lo", C.c_void_p),
+        ("B", C.c_int32), ("S", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
+        ("mode", C.c_int32), ("grid", C.c_int32), ("window", C.c_int32), ("causal", C.c_int32),
+        ("split_qk", C.c_int32), ("split_pv", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP kernels are the only compute path of this package. "
+            "Build them with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    lib.cvlm_abi_version.restype = C.c_int
+    lib.cvlm_target_arch.restype = C.c_char_p
+    for name in EXPORTS[2:]:
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> Optional[int]:
+    return torch.cuda.current_stream().cuda_stream or None
+
+
+class H2:
+    """Split-half tensor: two fp16 planes stored as one (2, *shape) fp16 tensor."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        assert t.dtype == torch.float16 and t.shape[0] == 2
+        self.t = t
+
+    @staticmethod
+    def empty(*shape, device="cuda") -> "H2":
+        return H2(torch.empty((2,) + tuple(shape), dtype=torch.float16, device=device))
+
+    @staticmethod
+    def zeros(*shape, device="cuda") -> "H2":
+        return H2(torch.zeros((2,) + tuple(shape), dtype=torch.float16, device=device))
+
+    @staticmethod
+    def pack(x: torch.Tensor) -> "H2":
+        """Host-side (torch) packing of weights / constants: hi = fp16(x), lo = fp16(x - hi)."""
+        x = x.float()
+        hi = x.half()
+        lo = (x - hi.float()).half()
+        return H2(torch.stack([hi, lo]).contiguous())
+
+    @property
+    def hi(self) -> torch.Tensor:
+        return self.t[0]
+
+    @property
+    def lo(self) -> torch.Tensor:
+        return self.t[1]
+
+    @property
+    def shape(self):
+        return self.t.shape[1:]
+
+    def float(self) -> torch.Tensor:
+        return self.t[0].float() + self.t[1].float()
+
+    def view(self, *shape) -> "H2":
+        return H2(self.t.view((2,) + tuple(shape)))
+
+
+def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw: Optional[int] = None,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, ldr: Optional[int] = None,
+         out_f32: Optional[torch.Tensor] = None, ldo: Optional[int] = None, out_h2: Optional[H2] = None,
+         ldoh: Optional[int] = None, alpha: float = 1.0, act: int = ACT_NONE, split: int = 3, batch: int = 1,
+         stride_a: int = 0, stride_w: int = 0, stride_r: int = 0, stride_o: int = 0, stride_oh: int = 0,
+         pixel_shuffle: Optional[Tuple[int, int, int]] = None) -> None:
+    g = GemmArgs()
+    g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
+    g.w_hi, g.w_lo, g.ldw, g.stride_w = w.hi.data_ptr(), w.lo.data_ptr(), ldw if ldw is not None else K, stride_w
+    g.bias = _p(bias)
+    g.residual, g.ldr, g.stride_r = _p(residual), (ldr if ldr is not None else N), stride_r
+    g.out_f32, g.ldo, g.stride_o = _p(out_f32), (ldo if ldo is not None else N), stride_o
+    if out_h2 is not None:
+        g.out_hi, g.out_lo = out_h2.hi.data_ptr(), out_h2.lo.data_ptr()
+    g.ldoh, g.stride_oh = (ldoh if ldoh is not None else N), stride_oh
+    g.M, g.N, g.K, g.batch = M, N, K, batch
+    g.alpha, g.act, g.split = alpha, act, split
+    if pixel_shuffle is not None:
+        g.ps_h, g.ps_w, g.ps_c2 = pixel_shuffle
+    _check(load().cvlm_gemm(C.byref(g), C.c_void_p(_stream())), "cvlm_gemm")
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, M: int, D: int, *,
+              ldx: Optional[int] = None, add: Optional[torch.Tensor] = None, add_rows: int = 0,
+              sum_out: Optional[torch.Tensor] = None, act: int = ACT_NONE, out_f32: Optional[torch.Tensor] = None,
+              out_h2: Optional[H2] = None) -> None:
+    _check(load().cvlm_layernorm(
+        C.c_void_p(x.data_ptr()), C.c_int64(ldx if ldx is not None else D), C.c_void_p(_p(add)), C.c_int32(add_rows),
+        C.c_void_p(_p(sum_out)), C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), C.c_float(eps),
+        C.c_int32(act), C.c_void_p(_p(out_f32)), C.c_void_p(out_h2.hi.data_ptr() if out_h2 else None),
+        C.c_void_p(out_h2.lo.data_ptr() if out_h2 else None), C.c_int32(M), C.c_int32(D), C.c_void_p(_stream())),
+        "cvlm_layernorm")
+
+
+def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], b_rows: int, M: int, D: int, *, scale: float = 1.0,
+             out_f32: Optional[torch.Tensor] = None, out_h2: Optional[H2] = None) -> None:
+    _check(load().cvlm_add_rows(
+        C.c_void_p(a.data_ptr()), C.c_void_p(_p(b)), C.c_int32(b_rows), C.c_float(scale), C.c_void_p(_p(out_f32)),
+        C.c_void_p(out_h2.hi.data_ptr() if out_h2 else None), C.c_void_p(out_h2.lo.data_ptr() if out_h2 else None),
+        C.c_int32(M), C.c_int32(D), C.c_void_p(_stream())), "cvlm_add_rows")
+
+
+def split_f32(x: torch.Tensor, out: H2) -> None:
+    _check(load().cvlm_split_f32(C.c_void_p(x.data_ptr()), C.c_void_p(out.hi.data_ptr()),
+                                 C.c_void_p(out.lo.data_ptr()), C.c_int64(x.numel()), C.c_void_p(_stream())),
+           "cvlm_split_f32")
+
+
+def patchify(src0: torch.Tensor, src1: Optional[torch.Tensor], p: int, out: H2, ldk: int) -> None:
+    B, C0, H, W = src0.shape
+    C1 = 0 if src1 is None else src1.shape[1]
+    _check(load().cvlm_patchify(
+        C.c_void_p(src0.data_ptr()), C.c_int32(C0), C.c_void_p(_p(src1)), C.c_int32(C1), C.c_int32(B), C.c_int32(H),
+        C.c_int32(W), C.c_int32(p), C.c_void_p(out.hi.data_ptr()), C.c_void_p(out.lo.data_ptr()), C.c_int32(ldk),
+        C.c_void_p(_stream())), "cvlm_patchify")
+
+
+def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, Cc: int, out: H2) -> None:
+    _check(load().cvlm_im2col3x3(C.c_void_p(x.data_ptr()), C.c_int32(B), C.c_int32(H), C.c_int32(W), C.c_int32(Cc),
+                                 C.c_void_p(out.hi.data_ptr()), C.c_void_p(out.lo.data_ptr()), C.c_void_p(_stream())),
+           "cvlm_im2col3x3")
+
+
+def reinterpret_transpose(x: torch.Tensor, B: int, T: int, D: int, out: H2) -> None:
+    _check(load().cvlm_reinterpret_transpose(C.c_void_p(x.data_ptr()), C.c_int32(B), C.c_int32(T), C.c_int32(D),
+                                             C.c_void_p(out.hi.data_ptr()), C.c_void_p(out.lo.data_ptr()),
+                                             C.c_void_p(_stream())), "cvlm_reinterpret_transpose")
+
+
+def attention(qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, *, mode: int = 0, grid: int = 0, window: int = 0,
+              causal: bool = False, pad: Optional[H2] = None, rel_h: Optional[H2] = None, rel_w: Optional[H2] = None,
+              split_qk: int = 3, split_pv: int = 3, scale: Optional[float] = None) -> None:
+    a = AttnArgs()
+    a.qkv_hi, a.qkv_lo = qkv.hi.data_ptr(), qkv.lo.data_ptr()
+    if pad is not None:
+        a.pad_hi, a.pad_lo = pad.hi.data_ptr(), pad.lo.data_ptr()
+    if rel_h is not None:
+        a.relh_hi, a.relh_lo = rel_h.hi.data_ptr(), rel_h.lo.data_ptr()
+        a.relw_hi, a.relw_lo = rel_w.hi.data_ptr(), rel_w.lo.data_ptr()
+    a.out_hi, a.out_lo = out.hi.data_ptr(), out.lo.data_ptr()
+    a.B, a.S, a.heads, a.hd = B, S, heads, hd
+    a.mode, a.grid, a.window, a.causal = mode, grid, window, int(causal)
+    a.split_qk, a.split_pv = split_qk, split_pv
+    a.scale = float(hd) ** -0.5 if scale is None else scale
+    _check(load().cvlm_attention(C.byref(a), C.c_void_p(_stream())), "cvlm_attention")
+
+
+def small_attention(q, k, v, out, B: int, nq: int, nk: int, heads: int, hd: int) -> None:
+    ld = heads * hd
+    _check(load().cvlm_small_attention(
+        C.c_void_p(q.data_ptr()), C.c_int64(ld), C.c_void_p(k.data_ptr()), C.c_int64(ld), C.c_void_p(v.data_ptr()),
+        C.c_int64(ld), C.c_void_p(out.data_ptr()), C.c_int64(ld), C.c_int32(B), C.c_int32(nq), C.c_int32(nk),
+        C.c_int32(heads), C.c_int32(hd), C.c_void_p(_stream())), "cvlm_small_attention")
+
+
+def dense_pe(gauss: torch.Tensor, size: int, Cc: int, out: torch.Tensor) -> None:
+    _check(load().cvlm_dense_pe(C.c_void_p(gauss.data_ptr()), C.c_int32(size), C.c_int32(Cc),
+                                C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), "cvlm_dense_pe")
+
+
+def mask_head(up, edge_emb, hyper, B: int, HW: int, Cc: int, low) -> None:
+    _check(load().cvlm_mask_head(C.c_void_p(up.data_ptr()), C.c_void_p(edge_emb.data_ptr()),
+                                 C.c_void_p(hyper.data_ptr()), C.c_int32(B), C.c_int32(HW), C.c_int32(Cc),
+                                 C.c_void_p(low.data_ptr()), C.c_void_p(_stream())), "cvlm_mask_head")
+
+
+def bilinear(x, N: int, hin: int, win: int, out, hout: int, wout: int, sigmoid_in: bool = False) -> None:
+    _check(load().cvlm_bilinear(C.c_void_p(x.data_ptr()), C.c_int32(N), C.c_int32(hin), C.c_int32(win),
+                                C.c_void_p(out.data_ptr()), C.c_int32(hout), C.c_int32(wout),
+                                C.c_int32(int(sigmoid_in)), C.c_void_p(_stream())), "cvlm_bilinear")
+
+
+def clip_assemble(patches, cls, pos, ctx, B: int, P: int, W: int, nctx: int, out) -> None:
+    _check(load().cvlm_clip_assemble(C.c_void_p(patches.data_ptr()), C.c_void_p(cls.data_ptr()),
+                                     C.c_void_p(pos.data_ptr()), C.c_void_p(ctx.data_ptr()), C.c_int32(B),
+                                     C.c_int32(P), C.c_int32(W), C.c_int32(nctx), C.c_void_p(out.data_ptr()),
+                                     C.c_void_p(_stream())), "cvlm_clip_assemble")
+
+
+def overwrite_rows(x, B: int, L: int, W: int, first: int, n: int, src) -> None:
+    _check(load().cvlm_overwrite_rows(C.c_void_p(x.data_ptr()), C.c_int32(B), C.c_int32(L), C.c_int32(W),
+                                      C.c_int32(first), C.c_int32(n), C.c_void_p(src.data_ptr()),
+                                      C.c_void_p(_stream())), "cvlm_overwrite_rows")
+
+
+def gather_rows(x, B: int, L: int, W: int, idx, fixed: int, out) -> None:
+    _check(load().cvlm_gather_rows(C.c_void_p(x.data_ptr()), C.c_int32(B), C.c_int32(L), C.c_int32(W),
+                                   C.c_void_p(_p(idx)), C.c_int32(fixed), C.c_void_p(out.data_ptr()),
+                                   C.c_void_p(_stream())), "cvlm_gather_rows")
+
+
+def clip_head(img, txt, logit_scale_exp: float, B: int, Cc: int, D: int, img_n, logits, pred, txt_sel) -> None:
+    _check(load().cvlm_clip_head(C.c_void_p(img.data_ptr()), C.c_void_p(txt.data_ptr()), C.c_float(logit_scale_exp),
+                                 C.c_int32(B), C.c_int32(Cc), C.c_int32(D), C.c_void_p(img_n.data_ptr()),
+                                 C.c_void_p(logits.data_ptr()), C.c_void_p(pred.data_ptr()),
+                                 C.c_void_p(txt_sel.data_ptr()), C.c_void_p(_stream())), "cvlm_clip_head")
+
+
+def normalize_add(x, add, R: int, D: int, out) -> None:
+    _check(load().cvlm_normalize_add(C.c_void_p(x.data_ptr()), C.c_void_p(_p(add)), C.c_int32(R), C.c_int32(D),
+                                     C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), "cvlm_normalize_add")

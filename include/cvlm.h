@@ -1,0 +1,169 @@
+/* cvlm.h -- C ABI of libcvlm_hip.so: the MI355X (gfx950) kernels behind the camouflaged-vlm
+ * cascaded forward pass.
+ *
+ * The reference (intcomp/camouflaged-vlm) is pure PyTorch and has NO FFI / plugin boundary
+ * (SURVEY.md §8b); its hot path calls torch eager ops.  This header is therefore the boundary the
+ * build defines: every entry point names the reference site (file:line, relative to the reference
+ * root) whose arithmetic it replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - launchers never allocate, never synchronise, never retain pointers; `stream` is a hipStream_t
+ *     passed as void* (NULL = default stream); workspace is caller-owned;
+ *   - return value: 0 on success, otherwise a hipError_t value or a negative CVLM_E_* code;
+ *   - tensors are row-major.  "f32" = float.  "h2" = split-half pair: two fp16 planes (hi, lo) of
+ *     identical shape, value = hi + lo; `lo` may be NULL where noted (fast mode, split = 1).
+ */
+#ifndef CVLM_H
+#define CVLM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVLM_ABI_VERSION 1
+#define CVLM_E_BADARG (-1)
+#define CVLM_E_UNSUPPORTED (-2)
+
+enum { CVLM_ACT_NONE = 0, CVLM_ACT_GELU = 1, CVLM_ACT_QUICKGELU = 2, CVLM_ACT_RELU = 3, CVLM_ACT_ABS_POST = 4 };
+
+int cvlm_abi_version(void);
+/* Device the library was built for ("gfx950") */
+const char* cvlm_target_arch(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM  out[z][m][n] = post( act( alpha * sum_k A[z][m][k] * W[z][n][k] + bias[n] ) + residual[z][m][n] )
+ * Replaces every nn.Linear / 1x1 / patch conv / ConvTranspose2d(k2,s2) on the path, e.g.
+ *   image_encoder.py:491 (qkv), :502 (proj), common.py:25 (MLP lin1/lin2), :651-659 (patch embed),
+ *   alpha_clip_rw/model.py:225,254 (in_proj/out_proj), :296-300 (c_fc/c_proj),
+ *   transformer_maskdecoder_edge.py:252-254,270 (decoder projections), mask_decoder_edge.py:53-59.
+ * A and W are h2 (K contiguous; lda/ldw in elements, multiples of 8; K multiple of 32).
+ * split = 3: hi*hi + lo*hi + hi*lo (needs both lo planes); split = 1: hi planes only.
+ * Outputs (any subset): out_f32 (ldo) and/or out h2 (ldoh).  ps_c2 > 0 selects the pixel-shuffle
+ * store used for ConvTranspose2d(k=2,s=2): row m = (b,y,x) on a ps_h x ps_w grid, column
+ * n = dy*ps_c2 + r  ->  out[((b*2*ps_h + 2y+dy) * 2*ps_w + 2x) * (ps_c2/2) + r].
+ * batch > 1 runs `batch` independent problems with the given element strides (0 = shared).
+ */
+typedef struct cvlm_gemm_args {
+    const void* a_hi; const void* a_lo; int64_t lda; int64_t stride_a;
+    const void* w_hi; const void* w_lo; int64_t ldw; int64_t stride_w;
+    const float* bias;
+    const float* residual; int64_t ldr; int64_t stride_r;
+    float* out_f32; int64_t ldo; int64_t stride_o;
+    void* out_hi; void* out_lo; int64_t ldoh; int64_t stride_oh;
+    int32_t M, N, K, batch;
+    float alpha;
+    int32_t act;
+    int32_t split;
+    int32_t ps_h, ps_w, ps_c2;
+} cvlm_gemm_args;
+int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
+
+/* Row LayerNorm over the last axis: y = LN(x + add) * gamma + beta, biased variance, then act.
+ * Replaces nn.LayerNorm (image_encoder.py:432,444; alpha_clip_rw/model.py:162-168;
+ * transformer_maskdecoder_edge.py:180-212) and LayerNorm2d on NHWC rows (common.py:31-43).
+ * x f32 [M][D] (ldx); add optional f32 [M % add_rows][D]; sum_out optional f32 (x + add);
+ * outputs: out_f32 and/or h2 (ld = D). */
+int cvlm_layernorm(const float* x, int64_t ldx, const float* add, int32_t add_rows, float* sum_out,
+                   const float* gamma, const float* beta, float eps, int32_t act,
+                   float* out_f32, void* out_hi, void* out_lo, int32_t M, int32_t D, void* stream);
+
+/* out = a + b[m % b_rows] (row-broadcast add), f32 and/or h2 outputs; scale applied to the sum.
+ * Replaces the PE adds / `x + pos_embed` / `src + dense` (image_encoder.py:140,
+ * transformer_maskdecoder_edge.py:177-209, mask_decoder_edge.py:157). */
+int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, float* out_f32,
+                  void* out_hi, void* out_lo, int32_t M, int32_t D, void* stream);
+
+/* f32 -> h2 planes (elementwise split), n elements. */
+int cvlm_split_f32(const float* x, void* out_hi, void* out_lo, int64_t n, void* stream);
+
+/* Patch gather for stride==kernel convolutions (image_encoder.py:651-659, :369-380;
+ * alpha_clip_rw/model.py:529-531).  src0 (B,C0,H,W) f32 and optional src1 (B,C1,H,W) f32 are cut
+ * into p x p patches; row m = (b, py, px); column k = c*p*p + iy*p + ix with the channels of src1
+ * appended after src0; columns K..ldk-1 are zero.  Output h2 [B*(H/p)*(W/p)][ldk]. */
+int cvlm_patchify(const float* src0, int32_t C0, const float* src1, int32_t C1, int32_t B, int32_t H,
+                  int32_t W, int32_t p, void* out_hi, void* out_lo, int32_t ldk, void* stream);
+
+/* 3x3 / pad 1 / stride 1 im2col on NHWC f32 (B,H,W,C): row m = (b,y,x), column k = (ky*3+kx)*C + c,
+ * zero padded borders.  Output h2 [B*H*W][9*C].  Serves the neck conv (image_encoder.py:106-112)
+ * and, with flipped weights, ConvTranspose2d(3,1,1) (mask_decoder_edge.py:88-93). */
+int cvlm_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, void* out_hi, void* out_lo,
+                   void* stream);
+
+/* Matrix transpose-reinterpretation used by PromptGenerator.init_embeddings (image_encoder.py:278-281):
+ * per image, the (T x D) f32 token matrix is re-read as (D x T) and transposed:
+ * out[b][t][c] = x_flat[b][c*T + t].  Output h2 [B*T][D]. */
+int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, void* out_hi, void* out_lo,
+                               void* stream);
+
+/* Fused multi-head attention (flash style, scores never materialised), replaces
+ *   image_encoder.py:488-504 + 589-625 (ViT-H window / global attention with decomposed rel-pos),
+ *   image_encoder.py:507-553 (window partition / unpartition incl. zero padding after norm1),
+ *   alpha_clip_rw/model.py:223-256 (CLIP ViT-L attention) and nn.MultiheadAttention with the causal
+ *   mask (alpha_clip_rw/model.py:388-390, 751-757).
+ * qkv: h2 [B*S_img][3*heads*hd] rows = tokens, columns [q | k | v], each heads*hd wide.
+ * mode 0: plain (S = tokens per image); mode 1: global with rel-pos on a grid x grid token map;
+ * mode 2: windows of `window` x `window` tokens on a grid x grid map, zero padded: pad tokens carry
+ *         q = k = v = qkv bias (pad_hi/pad_lo = h2 of the 3*heads*hd bias vector).
+ * rel_h/rel_w: h2 [(2*L-1)][hd] tables (L = grid or window).  scale = hd^-0.5 applied to q.k only.
+ * out: h2 [B*S_img][heads*hd]. */
+typedef struct cvlm_attn_args {
+    const void* qkv_hi; const void* qkv_lo;
+    const void* pad_hi; const void* pad_lo;
+    const void* relh_hi; const void* relh_lo;
+    const void* relw_hi; const void* relw_lo;
+    void* out_hi; void* out_lo;
+    int32_t B, S, heads, hd;
+    int32_t mode, grid, window, causal;
+    int32_t split_qk, split_pv;
+    float scale;
+} cvlm_attn_args;
+int cvlm_attention(const cvlm_attn_args* args, void* stream);
+
+/* Small fp32 attention for the two-way decoder (transformer_maskdecoder_edge.py:250-272):
+ * q f32 [B][nq][heads*hd] (ldq), k,v f32 [B][nk][heads*hd]; out f32 [B][nq][heads*hd].
+ * softmax(q.k / sqrt(hd)) v per head; any nq/nk. */
+int cvlm_small_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                         float* out, int64_t ldo, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
+                         void* stream);
+
+/* Dense positional encoding (models/sam_maskdecoder_edge.py:90-110): gauss f32 [2][C/2] ->
+ * out f32 [size*size][C] (token-major: row = y*size+x). */
+int cvlm_dense_pe(const float* gauss, int32_t size, int32_t C, float* out, void* stream);
+
+/* Mask head (mask_decoder_edge.py:181-186 + models/sam_maskdecoder_edge.py:380-387):
+ * up, edge_emb f32 NHWC [B][h][w][C]; hyper f32 [B][5][C] (rows 0..3 mask MLPs, row 4 edge MLP).
+ * low[b][y][x] = m*sigmoid(e) + m with m = hyper[b][0].up, e = hyper[b][4].edge_emb  (mask 0 only). */
+int cvlm_mask_head(const float* up, const float* edge_emb, const float* hyper, int32_t B, int32_t HW, int32_t C,
+                   float* low, void* stream);
+
+/* Bilinear resize, align_corners=False (F.interpolate): in f32 [N][hin][win] -> out [N][hout][wout];
+ * sigmoid_in != 0 applies sigmoid to the input first (demo.py:117-120). */
+int cvlm_bilinear(const float* in, int32_t N, int32_t hin, int32_t win, float* out, int32_t hout, int32_t wout,
+                  int32_t sigmoid_in, void* stream);
+
+/* CLIP token assembly (alpha_clip_rw/model.py:532-544): patches f32 [B][P][W] -> tokens f32
+ * [B][1+P+nctx][W] = [cls+pos0 | patches+pos | ctx]. */
+int cvlm_clip_assemble(const float* patches, const float* cls, const float* pos, const float* ctx,
+                       int32_t B, int32_t P, int32_t W, int32_t nctx, float* out, void* stream);
+
+/* Overwrite `n` consecutive token rows starting at row `first` of every sequence with `src` [n][W]
+ * (MaPLe deep prompts, alpha_clip_rw/model.py:319-355).  x f32 [B][L][W]. */
+int cvlm_overwrite_rows(float* x, int32_t B, int32_t L, int32_t W, int32_t first, int32_t n, const float* src,
+                        void* stream);
+
+/* Gather one row per sequence: out[b] = x[b][idx[b]] (idx NULL -> row `fixed`), x f32 [B][L][W]. */
+int cvlm_gather_rows(const float* x, int32_t B, int32_t L, int32_t W, const int32_t* idx, int32_t fixed,
+                     float* out, void* stream);
+
+/* CLIP head (cocotrainers/mapleAlphaCLIP.py:289-294): img f32 [B][D] (un-normalised), txt f32 [C][D]
+ * (= normalise(text features) + bank, precomputed), logit_scale_exp.  Outputs: img_n [B][D],
+ * logits [B][C], pred int64 [B], txt_sel [B][D] = txt[pred]. */
+int cvlm_clip_head(const float* img, const float* txt, float logit_scale_exp, int32_t B, int32_t C, int32_t D,
+                   float* img_n, float* logits, int64_t* pred, float* txt_sel, void* stream);
+
+/* Row L2 normalise + add: out[r] = x[r]/||x[r]|| + add[r] (text bank, mapleAlphaCLIP.py:290-291). */
+int cvlm_normalize_add(const float* x, const float* add, int32_t R, int32_t D, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVLM_H */

@@ -1,0 +1,288 @@
+"""Per-operator parity of the HIP kernels (through the C ABI) against fp64 torch-CPU restatements.
+
+Tolerances: split=3 (hi*hi + lo*hi + hi*lo) is the parity mode and is held to ~fp32 accuracy;
+split=1 (fp16 operands) is the fast mode and is held to fp16-operand accuracy.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from camouflaged_vlm_amd import hip as h
+    h.load()
+    return h
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32) * scale
+
+
+def dev_h2(hip, x):
+    return hip.H2(hip.H2.pack(x).t.cuda())
+
+
+def relerr(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 96), (70, 36, 64), (1000, 384, 1280)])
+@pytest.mark.parametrize("split", [3, 1])
+def test_gemm_plain(hip, M, N, K, split):
+    a, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    hip.gemm(A, W, M, N, K, out_f32=out, split=split)
+    if split == 3:
+        ref = A.float().cpu().double() @ W.float().cpu().double().t()
+        assert relerr(out, ref) < 2e-6
+    else:
+        ref = A.hi.float().cpu().double() @ W.hi.float().cpu().double().t()
+        assert relerr(out, ref) < 2e-6          # same fp16 operands, fp32 accumulate
+    ref32 = a.double() @ w.double().t()
+    assert relerr(out, ref32) < (1e-5 if split == 3 else 3e-3)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_epilogue(hip, act):
+    M, N, K = 200, 136, 64
+    a, w, bias, res = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.1), rnd(N, seed=5), rnd(M, N, seed=6)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    out = torch.empty(M, N, device="cuda")
+    oh = hip.H2.empty(M, N)
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), residual=res.cuda(), out_f32=out, out_h2=oh, act=act, alpha=0.5)
+    z = 0.5 * (A.float().cpu().double() @ W.float().cpu().double().t()) + bias.double()
+    z = {0: z, 1: F.gelu(z), 2: z * torch.sigmoid(1.702 * z), 3: F.relu(z)}[act] + res.double()
+    assert relerr(out, z) < 3e-6
+    assert relerr(oh.float(), z) < 3e-6
+
+
+def test_gemm_abs_post_and_batch(hip):
+    Bz, M, N, K = 3, 96, 80, 64
+    a, w, res = rnd(M, K, seed=7), rnd(Bz, N, K, seed=8), rnd(Bz, M, N, seed=9)
+    A, W = dev_h2(hip, a), dev_h2(hip, w.reshape(Bz * N, K))
+    out = torch.empty(Bz, M, N, device="cuda")
+    hip.gemm(A, W, M, N, K, residual=res.cuda(), out_f32=out, act=hip.ACT_ABS_POST, alpha=-1.0, batch=Bz,
+             stride_a=0, stride_w=N * K, stride_r=M * N, stride_o=M * N)
+    Wf = W.float().cpu().double().reshape(Bz, N, K)
+    ref = (res.double() - torch.einsum("mk,bnk->bmn", A.float().cpu().double(), Wf)).abs()
+    assert relerr(out, ref) < 3e-6
+
+
+def test_gemm_pixel_shuffle(hip):
+    Bn, H, Wd, Cin, Cout = 2, 6, 5, 64, 16
+    x = rnd(Bn, Cin, H, Wd, seed=10)
+    wt = rnd(Cin, Cout, 2, 2, seed=11, scale=0.1)
+    bias = rnd(Cout, seed=12)
+    ref = F.conv_transpose2d(x.double(), wt.double(), bias.double(), stride=2).permute(0, 2, 3, 1)  # NHWC
+    a = x.permute(0, 2, 3, 1).reshape(Bn * H * Wd, Cin)
+    wg = wt.permute(2, 3, 1, 0).reshape(4 * Cout, Cin)          # rows (dy, dx, co)
+    A, W = dev_h2(hip, a), dev_h2(hip, wg)
+    out = torch.full((Bn, 2 * H, 2 * Wd, Cout), float("nan"), device="cuda")
+    hip.gemm(A, W, Bn * H * Wd, 4 * Cout, Cin, bias=bias.repeat(4).cuda(), out_f32=out,
+             pixel_shuffle=(H, Wd, 2 * Cout))
+    assert relerr(out, ref) < 1e-5
+
+
+def test_layernorm(hip):
+    for M, D, eps in [(37, 1280, 1e-6), (10, 160, 1e-6), (5, 64, 1e-6), (300, 1024, 1e-5)]:
+        x, add = rnd(M, D, seed=13) * 3 + 1, rnd(7, D, seed=14)
+        g, b = rnd(D, seed=15), rnd(D, seed=16)
+        of, oh, so = torch.empty(M, D, device="cuda"), hip.H2.empty(M, D), torch.empty(M, D, device="cuda")
+        hip.layernorm(x.cuda(), g.cuda(), b.cuda(), eps, M, D, add=add.cuda(), add_rows=7, sum_out=so, act=1,
+                      out_f32=of, out_h2=oh)
+        s = x.double() + add.double()[torch.arange(M) % 7]
+        ref = F.gelu(F.layer_norm(s, (D,), g.double(), b.double(), eps))
+        assert relerr(so, s) < 1e-7
+        assert relerr(of, ref) < 3e-6
+        assert relerr(oh.float(), ref) < 3e-6
+
+
+def ref_attention(q, k, v, scale, bias=None, causal=False):
+    s = (q * scale) @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias
+    if causal:
+        L = s.shape[-1]
+        s = s + torch.full((L, L), float("-inf"), dtype=s.dtype).triu_(1)
+    return s.softmax(-1) @ v
+
+
+@pytest.mark.parametrize("split", [(3, 3), (3, 1), (1, 1)])
+@pytest.mark.parametrize("S,causal", [(581, False), (77, True), (64, False), (21, False)])
+def test_attention_plain(hip, S, causal, split):
+    Bn, Hh, hd = 2, 3, 64
+    D = Hh * hd
+    qkv = rnd(Bn * S, 3 * D, seed=17)
+    Q = dev_h2(hip, qkv)
+    out = hip.H2.empty(Bn * S, D)
+    out.t.fill_(float("nan"))
+    hip.attention(Q, out, Bn, S, Hh, hd, mode=0, causal=causal, split_qk=split[0], split_pv=split[1])
+    x = Q.float().cpu().double().reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4)
+    ref = ref_attention(x[0], x[1], x[2], hd ** -0.5, causal=causal).permute(0, 2, 1, 3).reshape(Bn * S, D)
+    tol = {(3, 3): 5e-6, (3, 1): 2e-3, (1, 1): 4e-3}[split]
+    assert relerr(out.float(), ref) < tol
+
+
+def relpos_bias(q, rel_h, rel_w, L):
+    """image_encoder.py:589-625 on (N, L*L, hd) queries."""
+    idx = torch.arange(L)[:, None] - torch.arange(L)[None, :] + (L - 1)
+    Rh, Rw = rel_h[idx], rel_w[idx]
+    rq = q.reshape(q.shape[0], L, L, -1)
+    bh = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
+    bw = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
+    return (bh[:, :, :, :, None] + bw[:, :, :, None, :]).reshape(q.shape[0], L * L, L * L)
+
+
+@pytest.mark.parametrize("split", [(3, 3), (1, 1)])
+@pytest.mark.parametrize("G", [20, 64])
+def test_attention_global_relpos(hip, G, split):
+    Bn, Hh, hd = (2, 2, 80) if G == 20 else (1, 2, 80)
+    D, S = Hh * hd, G * G
+    qkv = rnd(Bn * S, 3 * D, seed=18)
+    rel_h, rel_w = rnd(2 * G - 1, hd, seed=19, scale=0.2), rnd(2 * G - 1, hd, seed=20, scale=0.2)
+    Q, RH, RW = dev_h2(hip, qkv), dev_h2(hip, rel_h), dev_h2(hip, rel_w)
+    out = hip.H2.empty(Bn * S, D)
+    out.t.fill_(float("nan"))
+    hip.attention(Q, out, Bn, S, Hh, hd, mode=1, grid=G, rel_h=RH, rel_w=RW, split_qk=split[0], split_pv=split[1])
+    x = Q.float().cpu().double().reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).reshape(3, Bn * Hh, S, hd)
+    bias = relpos_bias(x[0], RH.float().cpu().double(), RW.float().cpu().double(), G)
+    ref = ref_attention(x[0], x[1], x[2], hd ** -0.5, bias=bias)
+    ref = ref.reshape(Bn, Hh, S, hd).permute(0, 2, 1, 3).reshape(Bn * S, D)
+    assert relerr(out.float(), ref) < (5e-6 if split == (3, 3) else 5e-3)
+
+
+@pytest.mark.parametrize("split", [(3, 3), (1, 1)])
+@pytest.mark.parametrize("G", [20, 64])
+def test_attention_window_relpos(hip, G, split):
+    ws, Bn, Hh, hd = 14, 2, 2, 80
+    D, S = Hh * hd, G * G
+    qkv = rnd(Bn * S, 3 * D, seed=21)
+    pad = rnd(3 * D, seed=22, scale=0.3)
+    rel_h, rel_w = rnd(2 * ws - 1, hd, seed=23, scale=0.2), rnd(2 * ws - 1, hd, seed=24, scale=0.2)
+    Q, P, RH, RW = dev_h2(hip, qkv), dev_h2(hip, pad), dev_h2(hip, rel_h), dev_h2(hip, rel_w)
+    out = hip.H2.empty(Bn * S, D)
+    out.t.fill_(float("nan"))
+    hip.attention(Q, out, Bn, S, Hh, hd, mode=2, grid=G, window=ws, pad=P, rel_h=RH, rel_w=RW,
+                  split_qk=split[0], split_pv=split[1])
+    # reference: pad the token map with the pad vector (= qkv of a zero token), partition, attend, unpartition
+    x = Q.float().cpu().double().reshape(Bn, G, G, 3 * D)
+    Gp = -(-G // ws) * ws
+    xp = P.float().cpu().double().expand(Bn, Gp, Gp, 3 * D).clone()
+    xp[:, :G, :G] = x
+    nw = Gp // ws
+    win = xp.reshape(Bn, nw, ws, nw, ws, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(Bn * nw * nw, ws * ws, 3, Hh, hd)
+    win = win.permute(2, 0, 3, 1, 4).reshape(3, -1, ws * ws, hd)
+    bias = relpos_bias(win[0], RH.float().cpu().double(), RW.float().cpu().double(), ws)
+    o = ref_attention(win[0], win[1], win[2], hd ** -0.5, bias=bias)
+    o = o.reshape(Bn * nw * nw, Hh, ws * ws, hd).permute(0, 2, 1, 3).reshape(Bn, nw, nw, ws, ws, D)
+    o = o.permute(0, 1, 3, 2, 4, 5).reshape(Bn, Gp, Gp, D)[:, :G, :G].reshape(Bn * S, D)
+    assert relerr(out.float(), o) < (5e-6 if split == (3, 3) else 5e-3)
+
+
+def test_small_attention(hip):
+    for (Bn, nq, nk, Hh, hd) in [(2, 6, 400, 8, 16), (2, 400, 6, 8, 16), (2, 6, 6, 8, 32), (1, 400, 2, 8, 16)]:
+        D = Hh * hd
+        q, k, v = rnd(Bn, nq, D, seed=25), rnd(Bn, nk, D, seed=26), rnd(Bn, nk, D, seed=27)
+        out = torch.empty(Bn, nq, D, device="cuda")
+        hip.small_attention(q.cuda(), k.cuda(), v.cuda(), out, Bn, nq, nk, Hh, hd)
+        sp = lambda t, n: t.double().reshape(Bn, n, Hh, hd).transpose(1, 2)
+        ref = ref_attention(sp(q, nq), sp(k, nk), sp(v, nk), 1 / math.sqrt(hd)).transpose(1, 2).reshape(Bn, nq, D)
+        assert relerr(out, ref) < 3e-6
+
+
+def test_patchify_and_im2col(hip):
+    Bn, H, Wd, p = 2, 28, 42, 14
+    img, al = rnd(Bn, 3, H, Wd, seed=28), rnd(Bn, 1, H, Wd, seed=29)
+    K = 4 * p * p
+    ldk = (K + 31) // 32 * 32
+    out = hip.H2.empty(Bn * (H // p) * (Wd // p), ldk)
+    out.t.fill_(float("nan"))
+    hip.patchify(img.cuda(), al.cuda(), p, out, ldk)
+    cat = torch.cat([img, al], 1)
+    ref = F.unfold(cat, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, K)     # (c, iy, ix) column order
+    got = out.float().cpu()
+    assert relerr(got[:, :K], ref) < 1e-6 and float(got[:, K:].abs().max()) == 0.0
+    Bn, H, Wd, Cc = 2, 9, 7, 32
+    x = rnd(Bn, H, Wd, Cc, seed=30)
+    out = hip.H2.empty(Bn * H * Wd, 9 * Cc)
+    hip.im2col3x3(x.cuda(), Bn, H, Wd, Cc, out)
+    u = F.unfold(x.permute(0, 3, 1, 2), kernel_size=3, padding=1)                   # (B, C*9, HW), (c, ky, kx)
+    ref = u.reshape(Bn, Cc, 9, H * Wd).permute(0, 3, 2, 1).reshape(Bn * H * Wd, 9 * Cc)
+    assert relerr(out.float(), ref) < 1e-6
+
+
+def test_misc_rowops(hip):
+    Bn, T, D = 2, 100, 48
+    x = rnd(Bn, T, D, seed=31)
+    out = hip.H2.empty(Bn * T, D)
+    hip.reinterpret_transpose(x.cuda(), Bn, T, D, out)
+    assert relerr(out.float(), x.reshape(Bn, D, T).permute(0, 2, 1).reshape(Bn * T, D)) < 1e-6
+    # dense PE
+    gm = rnd(2, 128, seed=32)
+    pe = torch.empty(20 * 20, 256, device="cuda")
+    hip.dense_pe(gm.cuda(), 20, 256, pe)
+    from oracle import cvlm_oracle as O
+    ref = O.dense_pe({"pe_layer.positional_encoding_gaussian_matrix": gm.double()}, 20).permute(1, 2, 0).reshape(400, 256)
+    assert float((pe.cpu().double() - ref).abs().max()) < 2e-5
+    # bilinear up x4 and down 1024->336 with sigmoid
+    a = rnd(2, 40, 40, seed=33)
+    up = torch.empty(2, 160, 160, device="cuda")
+    hip.bilinear(a.cuda(), 2, 40, 40, up, 160, 160)
+    assert relerr(up, F.interpolate(a.double()[:, None], (160, 160), mode="bilinear", align_corners=False)[:, 0]) < 1e-6
+    a = rnd(1, 320, 320, seed=34) * 3
+    dn = torch.empty(1, 56, 56, device="cuda")
+    hip.bilinear(a.cuda(), 1, 320, 320, dn, 56, 56, sigmoid_in=True)
+    # source coordinates are computed in fp32 like torch's fp32 CPU kernel (the reference's dtype)
+    ref = F.interpolate(torch.sigmoid(a)[:, None], (56, 56), mode="bilinear", align_corners=False)[:, 0]
+    assert relerr(dn, ref) < 3e-6
+    # mask head
+    Bn, HW, Cc = 2, 300, 32
+    u, e, h = rnd(Bn, HW, Cc, seed=35), rnd(Bn, HW, Cc, seed=36), rnd(Bn, 5, Cc, seed=37)
+    low = torch.empty(Bn, HW, device="cuda")
+    hip.mask_head(u.cuda(), e.cuda(), h.cuda(), Bn, HW, Cc, low)
+    m = torch.einsum("bpc,bc->bp", u.double(), h.double()[:, 0])
+    g = torch.sigmoid(torch.einsum("bpc,bc->bp", e.double(), h.double()[:, 4]))
+    assert relerr(low, m * g + m) < 3e-6
+    # clip head
+    Bn, Cc, D = 3, 61, 768
+    img, txt = rnd(Bn, D, seed=38), rnd(Cc, D, seed=39)
+    img_n, logits = torch.empty(Bn, D, device="cuda"), torch.empty(Bn, Cc, device="cuda")
+    pred, sel = torch.empty(Bn, dtype=torch.int64, device="cuda"), torch.empty(Bn, D, device="cuda")
+    hip.clip_head(img.cuda(), txt.cuda(), 100.0, Bn, Cc, D, img_n, logits, pred, sel)
+    n = img.double() / img.double().norm(dim=-1, keepdim=True)
+    rl = 100.0 * n @ txt.double().t()
+    assert relerr(img_n, n) < 1e-6 and relerr(logits, rl) < 3e-6
+    assert pred.cpu().tolist() == rl.argmax(1).tolist() and relerr(sel, txt[rl.argmax(1)]) == 0.0
+    # add_rows / split / assemble / overwrite / gather / normalize_add
+    a, b = rnd(10, 64, seed=40), rnd(5, 64, seed=41)
+    of, oh = torch.empty(10, 64, device="cuda"), hip.H2.empty(10, 64)
+    hip.add_rows(a.cuda(), b.cuda(), 5, 10, 64, scale=2.0, out_f32=of, out_h2=oh)
+    ref = 2.0 * (a + b[torch.arange(10) % 5])
+    assert relerr(of, ref) == 0.0 and relerr(oh.float(), ref) < 1e-6
+    pt, cls, pos, ctx = rnd(2, 16, 64, seed=42), rnd(64, seed=43), rnd(17, 64, seed=44), rnd(4, 64, seed=45)
+    tok = torch.empty(2, 21, 64, device="cuda")
+    hip.clip_assemble(pt.cuda(), cls.cuda(), pos.cuda(), ctx.cuda(), 2, 16, 64, 4, tok)
+    ref = torch.cat([torch.cat([cls.expand(2, 1, 64), pt], 1) + pos, ctx.expand(2, 4, 64)], 1)
+    assert relerr(tok, ref) == 0.0
+    src = rnd(4, 64, seed=46)
+    hip.overwrite_rows(tok, 2, 21, 64, 17, 4, src.cuda())
+    ref[:, 17:] = src
+    assert relerr(tok, ref) == 0.0
+    g0 = torch.empty(2, 64, device="cuda")
+    hip.gather_rows(tok, 2, 21, 64, torch.tensor([3, 20], dtype=torch.int32).cuda(), 0, g0)
+    assert relerr(g0, torch.stack([ref[0, 3], ref[1, 20]])) == 0.0
+    x, ad = rnd(5, 768, seed=47), rnd(5, 768, seed=48)
+    o = torch.empty(5, 768, device="cuda")
+    hip.normalize_add(x.cuda(), ad.cuda(), 5, 768, o)
+    assert relerr(o, x.double() / x.double().norm(dim=-1, keepdim=True) + ad.double()) < 1e-6
