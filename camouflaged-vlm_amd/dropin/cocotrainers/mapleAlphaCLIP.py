@@ -1,0 +1,157 @@
+"""Drop-in mirror of the reference's ``cocotrainers.mapleAlphaCLIP`` inference surface:
+``TestMaPLeAlphaCLIP(cfg, train_names, test_names).model`` -> ``CustomCLIP`` whose
+``forward(image, mask, label=None, train=False)`` returns
+``(image_features (B,1,768), text_features[pred] (B,1,768), pred (B,), logits (B,n_cls))``
+(reference: cocotrainers/mapleAlphaCLIP.py:229-294, 478-494).
+
+The module holds weights under the reference's state_dict keys and runs the
+MI355X HIP path (camouflaged_vlm_amd.engine.ClipModel).  The MaPLe text encoder is image
+independent, so it is evaluated once per weight load and cached (the reference recomputes it on
+every call); with torch.distributed initialised the class prompts are sharded over the ranks and the
+text features all-gathered (RCCL over xGMI) -- the only collective on the path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from camouflaged_vlm_amd import host, spec
+from camouflaged_vlm_amd.engine import ClipModel, Precision
+
+_BACKBONES = {"ViT-L/14@336px": dict(image_resolution=336, patch_size=14, vision_width=1024, vision_layers=24,
+                                     embed_dim=768, text_width=768, text_layers=12)}
+
+
+def geometry_from_cfg(cfg, n_train: int, n_test: int) -> spec.ClipGeometry:
+    name = cfg.MODEL.BACKBONE.NAME
+    if name not in _BACKBONES:
+        raise KeyError(f"unsupported CLIP backbone {name!r} (supported: {sorted(_BACKBONES)})")
+    size = cfg.INPUT.SIZE[0]
+    bb = _BACKBONES[name]
+    assert size == bb["image_resolution"], f"cfg_imsize ({size}) must equal to clip_imsize ({bb['image_resolution']})"
+    assert cfg.TRAINER.MAPLE.PROMPT_DEPTH >= 1, "For MaPLe, PROMPT_DEPTH should be >= 1"
+    return spec.ClipGeometry(n_ctx=cfg.TRAINER.MAPLE.N_CTX, prompt_depth=cfg.TRAINER.MAPLE.PROMPT_DEPTH,
+                             n_cls_train=n_train, n_cls_test=n_test, **bb)
+
+
+def gather_text_features(engine: ClipModel, eot: Sequence[int], split: str) -> torch.Tensor:
+    """Text features of all class prompts.  With N ranks each rank encodes a contiguous shard of
+    ceil(n/N) prompts and the (padded) shards are all-gathered, so every rank ends up with the
+    same (n, 768) tensor as a single-GPU run."""
+    import torch.distributed as dist
+    n = len(eot)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return engine.text_features(eot, split)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = -(-n // world)
+    lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+    D = engine.c.embed_dim
+    shard = torch.zeros(per, D, device=engine.device)
+    if hi > lo:
+        shard[:hi - lo] = engine.text_features(eot, split, rows=slice(lo, hi))
+    out = [torch.empty_like(shard) for _ in range(world)]
+    dist.all_gather(out, shard)
+    return torch.cat(out, 0)[:n].contiguous()
+
+
+class CustomCLIP(nn.Module):
+    def __init__(self, cfg=None, classnames=None, classnames_test=None, clip_model=None, *,
+                 geometry: Optional[spec.ClipGeometry] = None, eot_train: Optional[Sequence[int]] = None,
+                 eot_test: Optional[Sequence[int]] = None, seed: int = 0):
+        super().__init__()
+        if geometry is None:
+            geometry = geometry_from_cfg(cfg, len(classnames), len(classnames_test))
+        self.geometry = geometry
+        self.classnames, self.classnames_test = classnames, classnames_test
+        self.eot = {"train": list(eot_train) if eot_train is not None else None,
+                    "test": list(eot_test) if eot_test is not None else None}
+        host.populate(self, spec.clip_entries(geometry, prefix=""), seed=seed)
+        if clip_model is not None:
+            self._load_from_clip(clip_model)
+        self.dtype = torch.float32
+        self.train_text_features = None
+        self.test_text_features = None
+        self.precision: Optional[Precision] = None
+        self._engine: Optional[ClipModel] = None
+
+    # ---- weights -------------------------------------------------------------------------------
+    def _load_from_clip(self, clip_model) -> None:
+        """Copy weights from a CLIP state_dict / module using OpenAI key names (visual.*, transformer.*,
+        alpha_clip_rw/model.py:864-881 renames).  Token prefix/suffix buffers need the token embedding
+        table and tokenised prompts and are left to load_state_dict."""
+        sd = clip_model.state_dict() if hasattr(clip_model, "state_dict") else dict(clip_model)
+        own = dict(self.named_parameters())
+        own.update(dict(self.named_buffers()))
+        for k, v in sd.items():
+            if k.startswith("visual."):
+                nk = "image_encoder." + k[len("visual."):].replace("in_proj_weight", "in_proj.weight").replace(
+                    "in_proj_bias", "in_proj.bias")
+            elif k.startswith("transformer.") or k in ("positional_embedding", "text_projection") or k.startswith("ln_final."):
+                nk = "text_encoder." + k
+            elif k == "logit_scale":
+                nk = k
+            else:
+                continue
+            if nk in own and tuple(own[nk].shape) == tuple(v.shape):
+                own[nk].data.copy_(v.detach().float())
+
+    def load_text_features(self, train_text_features, test_text_features):
+        self.train_text_features = train_text_features
+        self.test_text_features = test_text_features
+        self._engine_text_dirty = True
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._engine = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._engine = None
+        return r
+
+    # ---- engine --------------------------------------------------------------------------------
+    def _eot(self, split: str):
+        if self.eot[split] is None:
+            names = self.classnames_test if split == "test" else self.classnames
+            self.eot[split] = host.eot_for_classes(names) if names is not None else spec.default_eot(self.geometry, split)
+        return self.eot[split]
+
+    def engine(self) -> ClipModel:
+        dev = self.logit_scale.device
+        if dev.type != "cuda":
+            raise RuntimeError("camouflaged_vlm_amd runs on MI355X only: move the model to a cuda (HIP) device; "
+                               "there is no CPU fallback")
+        if self._engine is None:
+            prec = self.precision or host.precision_from_env()
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._engine = ClipModel(sd, self.geometry, dev, prec, prefix="")
+            self._engine_text_dirty = True
+        if getattr(self, "_engine_text_dirty", True):
+            bank = self.test_text_features
+            if bank is None:
+                raise RuntimeError("text features not loaded: call load_text_features(train, test) first "
+                                   "(models/sam_maskdecoder_edge.py:190)")
+            feat = gather_text_features(self._engine, self._eot("test"), "test")
+            self._engine.set_text_bank(feat, bank, "test")
+            self._engine_text_dirty = False
+        return self._engine
+
+    def forward(self, image, mask, label=None, train=False):
+        if train:
+            raise NotImplementedError("training branch (mapleAlphaCLIP.py:267-280) is outside the inference path")
+        return self.engine().forward(image.float().contiguous(), mask.float().contiguous(), "test")
+
+
+class TestMaPLeAlphaCLIP(nn.Module):
+    """cocotrainers/mapleAlphaCLIP.py:478-494.  The reference downloads OpenAI weights here; this
+    build has no network, so weights start from the deterministic synthetic generator and are
+    expected to arrive through ``load_state_dict`` (demo.py:88-89) or ``clip_state_dict``."""
+
+    def __init__(self, cfg, classnames_train, classnames_test, clip_state_dict=None):
+        super().__init__()
+        self.classnames_train = classnames_train
+        self.classnames_test = classnames_test
+        self.model = CustomCLIP(cfg, classnames_train, classnames_test, clip_state_dict)

@@ -1,0 +1,610 @@
+"""Weight packing and kernel launch schedule of the cascaded forward pass on one MI355X.
+
+Everything numeric is a launch of libcvlm_hip.so through ``hip.py``; torch only owns device
+buffers (allocation, slicing, copies of constants).  All activations are token-major (NHWC): a
+(B, C, H, W) tensor of the reference is a [B*H*W][C] matrix here, so every Linear / 1x1 conv /
+ConvTranspose(2,2) is one NT GEMM and LayerNorm2d is a row LayerNorm.
+
+Schedules follow the reference line by line (cited per method); numeric format per tensor:
+f32 for residual streams and module outputs, h2 (split-half planes) for every GEMM/attention operand.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hip
+from .hip import ACT_ABS_POST, ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, H2
+from .spec import ClipGeometry, SamGeometry
+
+
+@dataclass(frozen=True)
+class Precision:
+    """split = 3: hi*hi + lo*hi + hi*lo products (fp32-grade, the parity mode); 1: fp16 operands."""
+    gemm: int = 3
+    qk: int = 3
+    pv: int = 3
+
+    @staticmethod
+    def named(name: str) -> "Precision":
+        return {"exact": Precision(3, 3, 3), "fast": Precision(1, 1, 1), "mixed": Precision(3, 3, 1)}[name]
+
+
+def _ceil(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Workspace:
+    """Named device buffers, allocated on first use and reused across calls."""
+
+    def __init__(self, device):
+        self.device = device
+        self._f32: Dict[tuple, torch.Tensor] = {}
+        self._h2: Dict[tuple, H2] = {}
+
+    def f32(self, name: str, *shape: int) -> torch.Tensor:
+        key = (name,) + tuple(shape)
+        t = self._f32.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.float32, device=self.device)
+            self._f32[key] = t
+        return t
+
+    def h2(self, name: str, *shape: int, zero: bool = False) -> H2:
+        key = (name,) + tuple(shape)
+        t = self._h2.get(key)
+        if t is None:
+            t = H2.zeros(*shape, device=self.device) if zero else H2.empty(*shape, device=self.device)
+            self._h2[key] = t
+        return t
+
+
+class Linear:
+    """Packed weight of one NT GEMM: rows scaled by a power of two so the lo plane stays in fp16's
+    normal range, K zero-padded to a multiple of 32, optional N padding (zero rows)."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device, n_pad: int = 0, k_pad: int = 0):
+        w = w.detach().float().reshape(w.shape[0], -1).cpu()
+        N, K = w.shape
+        self.N = max(N, n_pad)
+        self.K = max(_ceil(K, 32), k_pad)
+        wp = torch.zeros(self.N, self.K)
+        wp[:N, :K] = w
+        mx = float(wp.abs().max())
+        e = 0 if mx == 0.0 else int(math.floor(math.log2(2048.0 / mx)))
+        e = max(min(e, 24), -24)
+        self.alpha = float(2.0 ** (-e))
+        self.w = H2(H2.pack(wp * (2.0 ** e)).t.to(device))
+        self.bias = None
+        if b is not None:
+            bp = torch.zeros(self.N)
+            bp[:N] = b.detach().float().cpu()
+            self.bias = bp.to(device)
+
+
+class _Base:
+    def __init__(self, device, precision: Precision):
+        self.device = device
+        self.prec = precision
+        self.ws = Workspace(device)
+
+    def gemm(self, a: H2, lin: Linear, M: int, **kw) -> None:
+        kw.setdefault("split", self.prec.gemm)
+        alpha = kw.pop("alpha", 1.0)
+        if "bias" not in kw:
+            kw["bias"] = lin.bias
+        hip.gemm(a, lin.w, M, kw.pop("N", lin.N), lin.K, alpha=alpha * lin.alpha, **kw)
+
+    def dev(self, t) -> torch.Tensor:
+        return torch.as_tensor(t).detach().float().contiguous().to(self.device)
+
+
+# ================================================================================================
+# SAM-Adapter ViT encoder  (models/mmseg/models/sam/image_encoder.py:132-155)
+# ================================================================================================
+def lowpass_matrices(N: int, line: int):
+    """Real/imag parts of L = F^-1 diag(box) F with box = 1 on frequencies [-line, line): the
+    centred square zeroed by PromptGenerator.fft (image_encoder.py:335-343) is x -> L x L^T, so the
+    high-pass image is |x - Re(L x L^T)| = |x - Lr x Lr^T + Li x Li^T| (two dense projections)."""
+    k = np.arange(-line, line, dtype=np.float64)
+    d = np.arange(N, dtype=np.float64)
+    ang = 2.0 * np.pi * np.outer(d, k) / N            # angle for (n - m) = d, frequency k
+    c, s = np.cos(ang).sum(1) / N, np.sin(ang).sum(1) / N
+    idx = (np.arange(N)[:, None] - np.arange(N)[None, :]) % N
+    return torch.from_numpy(c[idx]).float(), torch.from_numpy(s[idx]).float()
+
+
+class SamEncoder(_Base):
+    def __init__(self, sd: Dict[str, torch.Tensor], g: SamGeometry, device, precision: Precision,
+                 prefix: str = "image_encoder."):
+        super().__init__(device, precision)
+        self.g = g
+        P = prefix
+        D, Pd = g.embed_dim, g.prompt_dim
+        L = lambda name, **kw: Linear(sd[P + name + ".weight"], sd.get(P + name + ".bias"), device, **kw)
+        self.patch = L("patch_embed.proj")
+        self.pos = self.dev(sd[P + "pos_embed"].reshape(g.grid * g.grid, D))
+        pg = "prompt_generator."
+        self.PK = _ceil(Pd, 32)                                   # padded prompt width (40 -> 64)
+        self.emb_gen = L(pg + "embedding_generator", n_pad=self.PK)
+        self.hc_proj = L(pg + "prompt_generator.proj", n_pad=self.PK)
+        self.shared = L(pg + "shared_mlp", k_pad=self.PK)
+        self.light = [L(f"{pg}lightweight_mlp_{i}.0", n_pad=self.PK, k_pad=self.PK) for i in range(g.depth)]
+        lr, li = lowpass_matrices(g.inp_size, g.fft_halfwidth)
+        self.lstack = H2(H2.pack(torch.cat([lr, li], 0)).t.to(device))       # [2N][N]
+        self.blocks = []
+        for i in range(g.depth):
+            b = f"blocks.{i}."
+            blk = dict(
+                n1w=self.dev(sd[P + b + "norm1.weight"]), n1b=self.dev(sd[P + b + "norm1.bias"]),
+                n2w=self.dev(sd[P + b + "norm2.weight"]), n2b=self.dev(sd[P + b + "norm2.bias"]),
+                qkv=L(b + "attn.qkv"), proj=L(b + "attn.proj"), lin1=L(b + "mlp.lin1"), lin2=L(b + "mlp.lin2"),
+                pad=H2(H2.pack(sd[P + b + "attn.qkv.bias"].detach().float().cpu()).t.to(device)),
+                rel_h=H2(H2.pack(sd[P + b + "attn.rel_pos_h"].detach().float().cpu()).t.to(device)),
+                rel_w=H2(H2.pack(sd[P + b + "attn.rel_pos_w"].detach().float().cpu()).t.to(device)),
+                window=0 if i in g.global_attn_indexes else g.window_size)
+            self.blocks.append(blk)
+        self.neck0 = L("neck.0")
+        w2 = sd[P + "neck.2.weight"].detach().float().cpu()                   # (O, I, 3, 3) -> (O, ky, kx, I)
+        self.neck2 = Linear(w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1), None, device)
+        self.nk1 = (self.dev(sd[P + "neck.1.weight"]), self.dev(sd[P + "neck.1.bias"]))
+        self.nk3 = (self.dev(sd[P + "neck.3.weight"]), self.dev(sd[P + "neck.3.bias"]))
+
+    # image_encoder.py:332-353
+    def highpass(self, inp: torch.Tensor) -> torch.Tensor:
+        B, C, N, _ = inp.shape
+        ws, sp = self.ws, self.prec.gemm
+        xs = ws.h2("hp_x", B * C * N, N)
+        hip.split_f32(inp, xs)
+        pq = ws.h2("hp_pq", B * C * 2 * N, N)                       # per plane: rows [0,N) = P^T, [N,2N) = Q^T
+        hip.gemm(self.lstack, xs, 2 * N, N, N, out_h2=pq, batch=B * C, stride_a=0, stride_w=N * N,
+                 stride_oh=2 * N * N, split=sp)
+        t = ws.f32("hp_t", B, C, N, N)
+        lr = H2(self.lstack.t[:, :N])
+        li = H2(self.lstack.t[:, N:])
+        hip.gemm(lr, pq, N, N, N, residual=inp, out_f32=t, alpha=-1.0, batch=B * C, stride_a=0,
+                 stride_w=2 * N * N, stride_r=N * N, stride_o=N * N, split=sp)
+        qt = H2(pq.t[:, N:])                                        # Q^T of plane 0; same per-plane stride
+        out = ws.f32("hp_out", B, C, N, N)
+        hip.gemm(li, qt, N, N, N, residual=t, out_f32=out, alpha=1.0, act=ACT_ABS_POST, batch=B * C, stride_a=0,
+                 stride_w=2 * N * N, stride_r=N * N, stride_o=N * N, split=sp)
+        return out
+
+    def forward(self, inp: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """inp (B,3,S,S) f32 on device -> features f32 [B*G*G][out_chans] (token-major NHWC)."""
+        g, ws, pr = self.g, self.ws, self.prec
+        B = inp.shape[0]
+        assert inp.shape[1:] == (3, g.inp_size, g.inp_size), \
+            f"Input image size {tuple(inp.shape[2:])} doesn't match model ({g.inp_size}*{g.inp_size})."
+        G, D, T = g.grid, g.embed_dim, g.grid * g.grid
+        M, PK = B * T, self.PK
+        KP = self.patch.K
+        # :134 patch embed
+        a0 = ws.h2("patches", M, KP)
+        hip.patchify(inp, None, g.patch_size, a0, KP)
+        x = ws.f32("x", M, D)
+        self.gemm(a0, self.patch, M, out_f32=x)
+        if taps is not None:
+            taps["patch_embed"] = x.clone()
+        # :136 init_embeddings -- (T x D) matrix re-read as (D x T) and transposed (reference quirk)
+        xt = ws.h2("xn", M, D)
+        hip.reinterpret_transpose(x, B, T, D, xt)
+        emb = ws.f32("emb", M, PK)
+        self.gemm(xt, self.emb_gen, M, out_f32=emb)
+        # :137 init_handcrafted: FFT high-pass -> patch conv
+        hp = self.highpass(inp)
+        if taps is not None:
+            taps["highpass"] = hp.clone()
+        hip.patchify(hp, None, g.patch_size, a0, KP)
+        hc = ws.f32("hc", M, PK)
+        self.gemm(a0, self.hc_proj, M, out_f32=hc)
+        feat = ws.h2("feat", M, PK)
+        hip.add_rows(hc, emb, M, M, PK, out_h2=feat)
+        # :140 pos embed
+        hip.add_rows(x, self.pos, T, M, D, out_f32=x)
+        xn = ws.h2("xn", M, D)
+        qkv = ws.h2("qkv", M, 3 * D)
+        att = ws.h2("att", M, D)
+        prm = ws.h2("prm", M, PK)
+        hid = ws.h2("hid", M, g.mlp_dim)
+        for i, blk in enumerate(self.blocks):
+            # :138/:145 prompt_i = shared_mlp(GELU(lightweight_mlp_i(feat))) ; x = prompt_i + x
+            self.gemm(feat, self.light[i], M, out_h2=prm, act=ACT_GELU)
+            self.gemm(prm, self.shared, M, residual=x, out_f32=x)
+            # :430-446 block
+            hip.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, M, D, out_h2=xn)
+            self.gemm(xn, blk["qkv"], M, out_h2=qkv)
+            if blk["window"] > 0:
+                hip.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
+                              pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv)
+            else:
+                hip.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
+                              rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv)
+            self.gemm(att, blk["proj"], M, residual=x, out_f32=x)
+            hip.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, M, D, out_h2=xn)
+            self.gemm(xn, blk["lin1"], M, out_h2=hid, act=ACT_GELU)
+            self.gemm(hid, blk["lin2"], M, residual=x, out_f32=x)
+            if taps is not None:
+                taps[f"block{i}"] = x.clone()
+        # :150 neck (LayerNorm2d == row LN on NHWC)
+        C = g.out_chans
+        hip.split_f32(x, xn)
+        c1 = ws.f32("neck_c1", M, C)
+        self.gemm(xn, self.neck0, M, out_f32=c1)
+        hip.layernorm(c1, self.nk1[0], self.nk1[1], 1e-6, M, C, out_f32=c1)
+        col = ws.h2("neck_col", M, 9 * C)
+        hip.im2col3x3(c1, B, G, G, C, col)
+        feats = ws.f32("features", M, C)
+        self.gemm(col, self.neck2, M, out_f32=feats)
+        hip.layernorm(feats, self.nk3[0], self.nk3[1], 1e-6, M, C, out_f32=feats)
+        return feats
+
+
+# ================================================================================================
+# Edge mask decoder  (models/mmseg/models/sam/mask_decoder_edge.py, transformer_maskdecoder_edge.py)
+# ================================================================================================
+class MaskDecoder(_Base):
+    def __init__(self, sd: Dict[str, torch.Tensor], g: SamGeometry, device, precision: Precision,
+                 prefix: str = "mask_decoder."):
+        super().__init__(device, precision)
+        self.g = g
+        P = prefix
+        C = g.prompt_embed_dim
+        self.lin: Dict[str, Linear] = {}
+        self.ln: Dict[str, tuple] = {}
+        names = {k[len(P):] for k in sd if k.startswith(P)}
+        for name in names:
+            if not name.endswith(".weight") or name in ("iou_token.weight", "mask_tokens.weight", "edge_token.weight"):
+                continue
+            stem, t = name[:-7], sd[P + name]
+            if t.dim() == 2 and stem + ".bias" in names:            # nn.Linear
+                self.lin[stem] = Linear(t, sd[P + stem + ".bias"], device)
+            elif t.dim() == 1:                                       # LayerNorm / LayerNorm2d
+                self.ln[stem] = (self.dev(t), self.dev(sd[P + stem + ".bias"]))
+        self.tokens = self.dev(torch.cat([sd[P + "iou_token.weight"], sd[P + "mask_tokens.weight"],
+                                          sd[P + "edge_token.weight"]], 0))                      # (6, C)
+
+        def convT2(name):                       # ConvTranspose2d(k2,s2): weight (in, out, 2, 2) -> rows (dy, dx, co)
+            w = sd[P + name + ".weight"].detach().float().cpu()
+            return Linear(w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]),
+                          sd[P + name + ".bias"].detach().float().cpu().repeat(4), device)
+
+        def convT3(name):                       # ConvTranspose2d(3,1,1) == conv3x3 with flipped taps
+            w = sd[P + name + ".weight"].detach().float().cpu()          # (in, out, 3, 3)
+            wf = torch.flip(w, dims=(2, 3)).permute(1, 2, 3, 0)           # (out, ky, kx, in)
+            return Linear(wf.reshape(wf.shape[0], -1), sd[P + name + ".bias"], device)
+
+        self.up = {n: (convT2(n + ".0"), convT2(n + ".3")) for n in ("output_upscaling", "embedding_encoder")}
+        self.mf = (convT3("embedding_maskfeature.0"), convT3("embedding_maskfeature.3"))
+        self.pe: Optional[torch.Tensor] = None
+
+    def _upscale(self, x_h2: H2, B: int, G: int, name: str, final_gelu: bool, out: torch.Tensor) -> torch.Tensor:
+        """mask_decoder_edge.py:53-59 / 82-87 on token-major input [B*G*G][C]."""
+        C, ws = self.g.prompt_embed_dim, self.ws
+        l0, l3 = self.up[name]
+        u1 = ws.f32(name + "_u1", B * 4 * G * G, C // 4)
+        self.gemm(x_h2, l0, B * G * G, out_f32=u1, pixel_shuffle=(G, G, 2 * (C // 4)))
+        u1h = ws.h2(name + "_u1h", B * 4 * G * G, C // 4)
+        w, b = self.ln[name + ".1"]
+        hip.layernorm(u1, w, b, 1e-6, B * 4 * G * G, C // 4, act=ACT_GELU, out_h2=u1h)
+        self.gemm(u1h, l3, B * 4 * G * G, out_f32=out, pixel_shuffle=(2 * G, 2 * G, 2 * (C // 8)),
+                  act=ACT_GELU if final_gelu else ACT_NONE)
+        return out
+
+    def _attn(self, name: str, q: H2, k: H2, v: H2, B: int, nq: int, nk: int, out: torch.Tensor) -> None:
+        """transformer_maskdecoder_edge.py:250-272."""
+        ws, heads = self.ws, self.g.dec_heads
+        I = self.lin[name + ".q_proj"].N
+        qp, kp, vp = ws.f32("a_q", B * nq, I), ws.f32("a_k", B * nk, I), ws.f32("a_v", B * nk, I)
+        self.gemm(q, self.lin[name + ".q_proj"], B * nq, out_f32=qp)
+        self.gemm(k, self.lin[name + ".k_proj"], B * nk, out_f32=kp)
+        self.gemm(v, self.lin[name + ".v_proj"], B * nk, out_f32=vp)
+        o = ws.f32("a_o", B * nq, I)
+        hip.small_attention(qp, kp, vp, o, B, nq, nk, heads, I // heads)
+        oh = ws.h2("a_oh", B * nq, I)
+        hip.split_f32(o, oh)
+        self.gemm(oh, self.lin[name + ".out_proj"], B * nq, out_f32=out)
+
+    def forward(self, feats: torch.Tensor, sparse: torch.Tensor, no_mask: torch.Tensor, gauss: torch.Tensor,
+                B: int, taps: Optional[dict] = None) -> torch.Tensor:
+        """feats f32 [B*T][C]; sparse f32 [B][2][C] -> low-res mask logits f32 [B][4G][4G] (mask 0, :133-135)."""
+        g, ws = self.g, self.ws
+        G, C, T = g.grid, g.prompt_embed_dim, g.grid * g.grid
+        if self.pe is None:
+            self.pe = torch.empty(T, C, device=self.device)
+            hip.dense_pe(gauss, G, C, self.pe)
+        fh = ws.h2("feats_h", B * T, C)
+        hip.split_f32(feats, fh)
+        edge_feat = self._upscale(fh, B, G, "embedding_encoder", False, ws.f32("edge_feat", B * 16 * T, C // 8))
+        # :150-158 tokens / src
+        NT = 6
+        queries = ws.f32("queries", B * NT, C)
+        queries.view(B, NT, C).copy_(self.tokens)
+        keys = ws.f32("keys", B * T, C)
+        hip.add_rows(feats, no_mask, 1, B * T, C, out_f32=keys)
+        cond_v = ws.h2("cond_v", B * 2, C)
+        cond_k = ws.h2("cond_k", B * 2, C)
+        hip.split_f32(sparse, cond_v)
+        hip.add_rows(sparse, None, 1, B * 2, C, scale=2.0, out_h2=cond_k)            # cond + cond_pe (:98-99)
+        qh, kh, vh = ws.h2("d_q", B * NT, C), ws.h2("d_k", B * T, C), ws.h2("d_v", B * T, C)
+        tq, tk = ws.h2("d_tq", B * NT, C), ws.h2("d_tk", B * NT, C)
+        ao_q, ao_k = ws.f32("ao_q", B * NT, C), ws.f32("ao_k", B * T, C)
+        hidh = ws.h2("d_hid", B * NT, g.dec_mlp)
+        mo = ws.f32("d_mlp", B * NT, C)
+        for i in range(g.dec_depth):
+            L = f"transformer.layers.{i}."
+            ln = lambda n: self.ln[L + n]
+            # self attention (:174-180); layer 0 replaces the queries
+            if i == 0:
+                hip.split_f32(queries, tq)
+                self._attn(L + "self_attn", tq, tq, tq, B, NT, NT, ao_q)
+                hip.layernorm(ao_q, *ln("norm1"), 1e-5, B * NT, C, out_f32=queries)
+            else:
+                hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=tq)
+                hip.split_f32(queries, tk)
+                self._attn(L + "self_attn", tq, tq, tk, B, NT, NT, ao_q)
+                hip.layernorm(queries, *ln("norm1"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries)
+            # tokens -> image (:183-187)
+            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
+            hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
+            hip.split_f32(keys, vh)
+            self._attn(L + "cross_attn_token_to_image", qh, kh, vh, B, NT, T, ao_q)
+            hip.layernorm(queries, *ln("norm2"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries)
+            # tokens -> cond (:189-193)
+            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
+            self._attn(L + "cross_attn_token_to_cond", qh, cond_k, cond_v, B, NT, 2, ao_q)
+            hip.layernorm(queries, *ln("norm2_cond"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries,
+                          out_h2=qh)
+            # MLP (:196-198)
+            self.gemm(qh, self.lin[L + "mlp.lin1"], B * NT, out_h2=hidh, act=ACT_RELU)
+            self.gemm(hidh, self.lin[L + "mlp.lin2"], B * NT, out_f32=mo)
+            hip.layernorm(queries, *ln("norm3"), 1e-5, B * NT, C, add=mo, add_rows=B * NT, out_f32=queries)
+            # image -> cond (:201-205): q = keys + pe, k = 2*cond, v = cond
+            self._attn(L + "cross_attn_image_to_cond", kh, cond_k, cond_v, B, T, 2, ao_k)
+            hip.layernorm(keys, *ln("norm4_cond"), 1e-5, B * T, C, add=ao_k, add_rows=B * T, out_f32=keys)
+            # image -> tokens (:208-212)
+            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
+            hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
+            hip.split_f32(queries, tq)
+            self._attn(L + "cross_attn_image_to_token", kh, qh, tq, B, T, NT, ao_k)
+            hip.layernorm(keys, *ln("norm4"), 1e-5, B * T, C, add=ao_k, add_rows=B * T, out_f32=keys)
+        # final token -> image attention (:103-107)
+        hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
+        hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
+        hip.split_f32(keys, vh)
+        self._attn("transformer.final_attn_token_to_image", qh, kh, vh, B, NT, T, ao_q)
+        hs = ws.f32("hs", B * NT, C)
+        hip.layernorm(queries, *self.ln["transformer.norm_final_attn"], 1e-5, B * NT, C, add=ao_q, add_rows=B * NT,
+                      out_f32=hs)
+        # :167-170 upscaling + edge feature head
+        up = self._upscale(vh, B, G, "output_upscaling", True, ws.f32("upscaled", B * 16 * T, C // 8))
+        HW = 16 * T
+        col1 = ws.h2("mf_col1", B * HW, 9 * (C // 8))
+        hip.im2col3x3(up, B, 4 * G, 4 * G, C // 8, col1)
+        m1 = ws.f32("mf_1", B * HW, C // 4)
+        self.gemm(col1, self.mf[0], B * HW, out_f32=m1)
+        hip.layernorm(m1, *self.ln["embedding_maskfeature.1"], 1e-6, B * HW, C // 4, act=ACT_GELU, out_f32=m1)
+        col2 = ws.h2("mf_col2", B * HW, 9 * (C // 4))
+        hip.im2col3x3(m1, B, 4 * G, 4 * G, C // 4, col2)
+        edge_emb = ws.f32("edge_emb", B * HW, C // 8)
+        self.gemm(col2, self.mf[1], B * HW, residual=edge_feat, out_f32=edge_emb)
+        # :172-186 hyper-network rows actually used: mask token 0 (hs row 1) and edge token (hs row 5)
+        hyper = ws.f32("hyper", B, 5, C // 8)
+        row, rowh = ws.f32("h_row", B, C), ws.h2("h_rowh", B, C)
+        t1, t2 = ws.h2("h_t1", B, C), ws.h2("h_t2", B, C)
+        for tok_row, mlp, slot in ((1, "output_hypernetworks_mlps.0", 0), (5, "edge_mlp", 4)):
+            hip.gather_rows(hs, B, NT, C, None, tok_row, row)
+            hip.split_f32(row, rowh)
+            self.gemm(rowh, self.lin[mlp + ".layers.0"], B, out_h2=t1, act=ACT_RELU)
+            self.gemm(t1, self.lin[mlp + ".layers.1"], B, out_h2=t2, act=ACT_RELU)
+            self.gemm(t2, self.lin[mlp + ".layers.2"], B, out_f32=hyper[:, slot], ldo=5 * (C // 8))
+        low = ws.f32("low", B, HW)
+        hip.mask_head(up, edge_emb, hyper, B, HW, C // 8, low)
+        if taps is not None:
+            taps.update(hs=hs.clone(), src=keys.clone(), upscaled=up.clone(), edge_emb=edge_emb.clone(),
+                        hyper=hyper.clone(), low_res_masks=low.clone())
+        return low
+
+
+# ================================================================================================
+# MaPLe / Alpha-CLIP  (alpha_clip_rw/model.py:507-563, cocotrainers/mapleAlphaCLIP.py:55-78,210-294)
+# ================================================================================================
+class ClipModel(_Base):
+    def __init__(self, sd: Dict[str, torch.Tensor], c: ClipGeometry, device, precision: Precision,
+                 prefix: str = "clip_model."):
+        super().__init__(device, precision)
+        self.c = c
+        self.sd_prefix = prefix
+        P = prefix
+        ie, te, pl = P + "image_encoder.", P + "text_encoder.", P + "prompt_learner."
+        W = c.vision_width
+        wcat = torch.cat([sd[ie + "conv1.weight"].detach().float().cpu().reshape(W, -1),
+                          sd[ie + "conv1_alpha.weight"].detach().float().cpu().reshape(W, -1)], 1)
+        self.conv = Linear(wcat, None, device)
+        self.cls = self.dev(sd[ie + "class_embedding"])
+        self.pos = self.dev(sd[ie + "positional_embedding"])
+        self.ln_pre = (self.dev(sd[ie + "ln_pre.weight"]), self.dev(sd[ie + "ln_pre.bias"]))
+        self.ln_post = (self.dev(sd[ie + "ln_post.weight"]), self.dev(sd[ie + "ln_post.bias"]))
+        self.vproj = Linear(sd[ie + "proj"].detach().float().cpu().t().contiguous(), None, device)
+
+        def block(p, text):
+            ipw = sd[p + ("attn.in_proj_weight" if text else "attn.in_proj.weight")]
+            ipb = sd[p + ("attn.in_proj_bias" if text else "attn.in_proj.bias")]
+            return dict(inp=Linear(ipw, ipb, device),
+                        out=Linear(sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], device),
+                        fc=Linear(sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], device),
+                        pj=Linear(sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], device),
+                        ln1=(self.dev(sd[p + "ln_1.weight"]), self.dev(sd[p + "ln_1.bias"])),
+                        ln2=(self.dev(sd[p + "ln_2.weight"]), self.dev(sd[p + "ln_2.bias"])))
+
+        self.vblocks = [block(f"{ie}transformer.resblocks.{i}.", False) for i in range(c.vision_layers)]
+        self.tblocks = [block(f"{te}transformer.resblocks.{i}.", True) for i in range(c.text_layers)]
+        self.tpos = self.dev(sd[te + "positional_embedding"])
+        self.ln_final = (self.dev(sd[te + "ln_final.weight"]), self.dev(sd[te + "ln_final.bias"]))
+        self.tproj = Linear(sd[te + "text_projection"].detach().float().cpu().t().contiguous(), None, device)
+        self.logit_scale_exp = float(torch.as_tensor(sd[P + "logit_scale"]).detach().float().exp())
+        # MaPLe prompts (mapleAlphaCLIP.py:210-227): shared ctx and deep visual prompts are weight-only
+        self.ctx = self.dev(sd[pl + "ctx"])
+        self.deep_text = [self.dev(sd[f"{pl}compound_prompts_text.{i}"]) for i in range(c.prompt_depth - 1)]
+        proj = Linear(sd[pl + "proj.weight"], sd[pl + "proj.bias"], device)
+        self.shared_ctx = torch.empty(c.n_ctx, W, device=device)
+        ch = H2.empty(c.n_ctx, c.text_width, device=device)
+        hip.split_f32(self.ctx, ch)
+        self.gemm(ch, proj, c.n_ctx, out_f32=self.shared_ctx)
+        self.deep_vis = []
+        for i in range(c.prompt_depth - 1):
+            lin = Linear(sd[f"{pl}compound_prompt_projections.{i}.weight"],
+                         sd[f"{pl}compound_prompt_projections.{i}.bias"], device)
+            hip.split_f32(self.deep_text[i], ch)
+            o = torch.empty(c.n_ctx, W, device=device)
+            self.gemm(ch, lin, c.n_ctx, out_f32=o)
+            self.deep_vis.append(o)
+        self.prefix = {s: self.dev(sd[pl + "token_prefix" + ("_test" if s == "test" else "")]) for s in ("train", "test")}
+        self.suffix = {s: self.dev(sd[pl + "token_suffix" + ("_test" if s == "test" else "")]) for s in ("train", "test")}
+        self.txt: Dict[str, torch.Tensor] = {}
+
+    def _blocks(self, x: torch.Tensor, blocks, Bn: int, L: int, Wd: int, heads: int, deep, first_row: int,
+                causal: bool) -> None:
+        """alpha_clip_rw/model.py:315-362 / 392-434: residual attention blocks on x f32 [Bn][L][Wd] (in place)."""
+        ws, pr, c = self.ws, self.prec, self.c
+        M = Bn * L
+        tag = "t" if causal else "v"
+        xn, qkv, att = ws.h2(tag + "xn", M, Wd), ws.h2(tag + "qkv", M, 3 * Wd), ws.h2(tag + "att", M, Wd)
+        hid = ws.h2(tag + "hid", M, 4 * Wd)
+        for i, blk in enumerate(blocks):
+            if 1 <= i <= len(deep):
+                hip.overwrite_rows(x, Bn, L, Wd, first_row, c.n_ctx, deep[i - 1])
+            hip.layernorm(x, *blk["ln1"], 1e-5, M, Wd, out_h2=xn)
+            self.gemm(xn, blk["inp"], M, out_h2=qkv)
+            hip.attention(qkv, att, Bn, L, heads, Wd // heads, mode=0, causal=causal, split_qk=pr.qk, split_pv=pr.pv)
+            self.gemm(att, blk["out"], M, residual=x, out_f32=x)
+            hip.layernorm(x, *blk["ln2"], 1e-5, M, Wd, out_h2=xn)
+            self.gemm(xn, blk["fc"], M, out_h2=hid, act=ACT_QUICKGELU)
+            self.gemm(hid, blk["pj"], M, residual=x, out_f32=x)
+
+    def image_features(self, image: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+        """alpha_clip_rw/model.py:528-563 -> f32 [B][embed_dim] (un-normalised)."""
+        c, ws = self.c, self.ws
+        B = image.shape[0]
+        P, Wd, L = c.grid * c.grid, c.vision_width, c.n_tokens
+        pt = ws.h2("cpatch", B * P, self.conv.K)
+        hip.patchify(image, alpha, c.patch_size, pt, self.conv.K)
+        pe = ws.f32("cpe", B * P, Wd)
+        self.gemm(pt, self.conv, B * P, out_f32=pe)
+        x = ws.f32("cx", B, L, Wd)
+        hip.clip_assemble(pe, self.cls, self.pos, self.shared_ctx, B, P, Wd, c.n_ctx, x)
+        hip.layernorm(x, *self.ln_pre, 1e-5, B * L, Wd, out_f32=x)
+        self._blocks(x, self.vblocks, B, L, Wd, c.vision_heads, self.deep_vis, L - c.n_ctx, causal=False)
+        cls = ws.f32("ccls", B, Wd)
+        hip.gather_rows(x, B, L, Wd, None, 0, cls)
+        ch = ws.h2("cclsh", B, Wd)
+        hip.layernorm(cls, *self.ln_post, 1e-5, B, Wd, out_h2=ch)
+        out = ws.f32("cfeat", B, c.embed_dim)
+        self.gemm(ch, self.vproj, B, out_f32=out)
+        return out
+
+    def text_features(self, eot: Sequence[int], split: str = "test", rows: Optional[slice] = None) -> torch.Tensor:
+        """mapleAlphaCLIP.py:64-78 on the MaPLe prompts; image independent.  Sequences are truncated to
+        max(eot)+1 positions, which is exact under the causal mask.  -> f32 [n][embed_dim]."""
+        c = self.c
+        pre, suf = self.prefix[split], self.suffix[split]
+        eot = list(int(e) for e in eot)
+        if rows is not None:
+            pre, suf, eot = pre[rows], suf[rows], eot[rows]
+        n = pre.shape[0]
+        L, Wd = max(eot) + 1, c.text_width
+        full = torch.cat([pre, self.ctx.unsqueeze(0).expand(n, -1, -1), suf], dim=1)[:, :L].contiguous()
+        x = torch.empty(n, L, Wd, device=self.device)
+        hip.add_rows(full, self.tpos[:L].contiguous(), L, n * L, Wd, out_f32=x)
+        self._blocks(x, self.tblocks, n, L, Wd, c.text_heads, self.deep_text, 1, causal=True)
+        rows_f = torch.empty(n, Wd, device=self.device)
+        hip.gather_rows(x, n, L, Wd, torch.tensor(eot, dtype=torch.int32, device=self.device), 0, rows_f)
+        rh = H2.empty(n, Wd, device=self.device)
+        hip.layernorm(rows_f, *self.ln_final, 1e-5, n, Wd, out_h2=rh)
+        out = torch.empty(n, c.embed_dim, device=self.device)
+        self.gemm(rh, self.tproj, n, out_f32=out)
+        return out
+
+    def set_text_bank(self, text_feat: torch.Tensor, bank: torch.Tensor, split: str = "test") -> None:
+        """txt = normalise(text_feat) + bank, no re-normalisation (mapleAlphaCLIP.py:290-291)."""
+        n, D = text_feat.shape
+        out = torch.empty(n, D, device=self.device)
+        hip.normalize_add(text_feat, self.dev(bank), n, D, out)
+        self.txt[split] = out
+
+    def forward(self, image: torch.Tensor, alpha: torch.Tensor, split: str = "test"):
+        """CustomCLIP.forward test branch (mapleAlphaCLIP.py:281-294)."""
+        B = image.shape[0]
+        txt = self.txt[split]
+        feat = self.image_features(image, alpha)
+        n, D = txt.shape
+        img_n = torch.empty(B, D, device=self.device)
+        logits = torch.empty(B, n, device=self.device)
+        pred = torch.empty(B, dtype=torch.int64, device=self.device)
+        sel = torch.empty(B, D, device=self.device)
+        hip.clip_head(feat, txt, self.logit_scale_exp, B, n, D, img_n, logits, pred, sel)
+        return img_n.unsqueeze(1), sel.unsqueeze(1), pred, logits
+
+
+# ================================================================================================
+# The cascade  (models/sam_maskdecoder_edge.py:331-357 + demo.py:116-122)
+# ================================================================================================
+class Cascade(_Base):
+    def __init__(self, sd: Dict[str, torch.Tensor], g: SamGeometry, c: ClipGeometry, device,
+                 precision: Precision = Precision(), clip: Optional[ClipModel] = None):
+        super().__init__(device, precision)
+        self.g, self.c = g, c
+        self.encoder = SamEncoder(sd, g, device, precision)
+        self.decoder = MaskDecoder(sd, g, device, precision)
+        self.clip = clip if clip is not None else ClipModel(sd, c, device, precision)
+        self.no_mask = self.dev(sd["no_mask_embed.weight"].reshape(1, -1))
+        self.gauss = self.dev(sd["pe_layer.positional_encoding_gaussian_matrix"])
+        self.vproj = (self.dev(sd["sam_visual_proj.0.weight"]), self.dev(sd["sam_visual_proj.0.bias"]),
+                      Linear(sd["sam_visual_proj.1.weight"], sd["sam_visual_proj.1.bias"], device),
+                      self.dev(sd["sam_visual_proj.2.weight"]), self.dev(sd["sam_visual_proj.2.bias"]))
+        self.tproj = (self.dev(sd["sam_text_proj.0.weight"]), self.dev(sd["sam_text_proj.0.bias"]),
+                      Linear(sd["sam_text_proj.1.weight"], sd["sam_text_proj.1.bias"], device))
+
+    def sparse_prompts(self, img_f: torch.Tensor, txt_f: torch.Tensor, B: int) -> torch.Tensor:
+        """models/sam_maskdecoder_edge.py:342-344."""
+        ws, C = self.ws, self.g.prompt_embed_dim
+        h = ws.h2("sp_h", B, 768)
+        sparse = ws.f32("sparse", B, 2, C)
+        tmp = ws.f32("sp_tmp", B, C)
+        hip.layernorm(img_f.reshape(B, 768), self.vproj[0], self.vproj[1], 1e-5, B, 768, out_h2=h)
+        self.gemm(h, self.vproj[2], B, out_f32=tmp)
+        hip.layernorm(tmp, self.vproj[3], self.vproj[4], 1e-5, B, C, out_f32=tmp)
+        sparse[:, 0].copy_(tmp)
+        hip.layernorm(txt_f.reshape(B, 768), self.tproj[0], self.tproj[1], 1e-5, B, 768, out_h2=h)
+        self.gemm(h, self.tproj[2], B, out_f32=tmp)
+        sparse[:, 1].copy_(tmp)
+        return sparse
+
+    def infer_test(self, inp, clip_image, clip_mask, taps: Optional[dict] = None) -> torch.Tensor:
+        g = self.g
+        B = inp.shape[0]
+        feats = self.encoder.forward(inp, taps)
+        img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
+        sparse = self.sparse_prompts(img_f, txt_f, B)
+        low = self.decoder.forward(feats, sparse, self.no_mask, self.gauss, B, taps)
+        masks = torch.empty(B, 1, g.inp_size, g.inp_size, device=self.device)
+        hip.bilinear(low, B, 4 * g.grid, 4 * g.grid, masks, g.inp_size, g.inp_size)   # :380-387 (2nd resize = identity)
+        if taps is not None:
+            taps.update(features=feats.clone(), sparse=sparse.clone(), pass1_logits=score.clone())
+        return masks
+
+    def stage2(self, mask_logits: torch.Tensor, clip_image: torch.Tensor):
+        """demo.py:117-122: alpha = resize(sigmoid(mask)) -> clip_model(image, alpha)."""
+        B, R = mask_logits.shape[0], self.c.image_resolution
+        alpha = self.ws.f32("alpha2", B, 1, R, R)
+        hip.bilinear(mask_logits, B, self.g.inp_size, self.g.inp_size, alpha, R, R, sigmoid_in=True)
+        return self.clip.forward(clip_image, alpha)
+
+    def cascade(self, inp, clip_image, clip_mask):
+        masks = self.infer_test(inp, clip_image, clip_mask)
+        _, _, pred, logits = self.stage2(masks, clip_image)
+        return masks, pred, logits
