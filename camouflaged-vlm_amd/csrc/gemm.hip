@@ -1,12 +1,15 @@
 // Split-half MFMA GEMM for gfx950:  out = post(act(alpha * A . W^T + bias) + residual)
 //
 // Both operands arrive as fp16 planes with K contiguous ("NT" form: activations [M][K], torch
-// Linear weights [N][K]).  A 128x128 output tile per 256-thread workgroup (2x2 waves, 64x64 per
-// wave, 4x4 MFMA 16x16x32 f16 tiles), BK = 32, LDS double-buffered and filled by 16-byte
-// global->LDS DMA (global_load_lds_dwordx4) so the next K-tile streams in under the MFMAs of the
-// current one.  The LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128
-// fragment reads are removed by permuting the 16-byte chunks of each 64-byte row on the *source*
-// address and applying the same involution on the read (guide §5.4 rule 21).
+// Linear weights [N][K]).  Workgroup tile (WM*64) x (WN*64), one wave per 64x64 sub-tile (4x4 MFMA
+// 16x16x32 f16 tiles), BK = 32.  K-tiles stream through an NSTAGE-deep LDS ring filled by 16-byte
+// global->LDS DMA (global_load_lds_dwordx4):
+//   NSTAGE = 2: one tile ahead, __syncthreads() per K-tile (drains the DMA);
+//   NSTAGE = 3: two tiles ahead, counted s_waitcnt vmcnt(N) + raw s_barrier so the newest tile's DMA
+//               stays in flight across the barrier (guide §5 "Pipelining across barriers").
+// The LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128 fragment reads
+// are removed by permuting the 16-byte chunks of each 64-byte row on the *source* address and
+// applying the same involution on the read (guide §5.4 rule 21).
 //
 // The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that each
 // lane ends up with 4 consecutive output columns of one output row: the epilogue then stores
@@ -15,12 +18,12 @@
 // split == 3: acc += Whi.Ahi + Wlo.Ahi + Whi.Alo  (fp32 accumulate; ~2^-22 relative products)
 // split == 1: acc += Whi.Ahi
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/cvlm.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int PLANE_BYTES = 128 * BK * 2;          // one 128-row fp16 plane of a K-tile: 8 KiB
+constexpr int BK_MIN = 32;
 
 // chunk permutation g(q), q = (row >> 2) & 3 (derived for the ds_read_b128 lane groups)
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
@@ -28,17 +31,30 @@ __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
 struct GemmParams {
     cvlm_gemm_args a;
     int nbx, nby;
+    int group_m;       // tile rows per L2 super-tile (consecutive ids walk group_m x nbx tiles column-major)
 };
 
-template <int SPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
-    constexpr int NPL = (SPLIT == 3) ? 4 : 2;          // planes per stage: Ahi [Alo] Whi [Wlo]
-    constexpr int STAGE = NPL * PLANE_BYTES;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
+    constexpr int WROWS = MT * 16;                                  // activation rows per wave
+    constexpr int BM = WM * WROWS, BN = WN * 64, NWAVE = WM * WN;
+    constexpr int NPA = (SPLIT == 3) ? 2 : 1;                       // planes per operand
+    constexpr int A_PLANE = BM * BK * 2, W_PLANE = BN * BK * 2;     // bytes
+    constexpr int STAGE = NPA * (A_PLANE + W_PLANE);
+    constexpr int ROWB = BK * 2;                                    // bytes per tile row (64 or 128)
+    constexpr int RPI = 1024 / ROWB;                                // rows per 1-KiB DMA instruction (16 or 8)
+    constexpr int CPR = ROWB / 16;                                  // 16-byte chunks per row (4 or 8)
+    constexpr int A_INSTR = BM / RPI, W_INSTR = BN / RPI;           // DMA instructions per plane
+    constexpr int TOTAL = NPA * (A_INSTR + W_INSTR);
+    static_assert(TOTAL % NWAVE == 0, "staging must divide evenly over the waves");
+    constexpr int PER_WAVE = TOTAL / NWAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const cvlm_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
 
     // ---- tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
     const int ntiles = p.nbx * p.nby;
@@ -47,7 +63,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = pid & 7, idx = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int by = pid / p.nbx, bx = pid - by * p.nbx;
+    // grouped order: the workgroups co-resident on one XCD cover a (group_m x n) patch of tiles, so each
+    // A / W k-slice they stream is fetched from HBM/L3 once and hit in the XCD's L2 afterwards.
+    int by, bx;
+    {
+        const int per_group = p.group_m * p.nbx;
+        const int grp = pid / per_group;
+        const int first = grp * p.group_m;
+        const int gm = (p.nby - first) < p.group_m ? (p.nby - first) : p.group_m;
+        const int rem = pid - grp * per_group;
+        by = first + rem % gm;
+        bx = rem / gm;
+    }
     const int bm = by * BM, bn = bx * BN;
     const int z = blockIdx.y;
 
@@ -56,87 +83,115 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     const half_t* Whi = (const half_t*)g.w_hi + (int64_t)z * g.stride_w;
     const half_t* Wlo = (const half_t*)g.w_lo + (int64_t)z * g.stride_w;
 
-    // ---- staging assignment: NPL*8 wave-instructions (16 rows x 64 B each) per stage, spread over 4 waves
-    constexpr int PER_WAVE = NPL * 8 / 4;
+    // ---- staging assignment.  Stage layout: [Ahi][Alo][Whi][Wlo]; instruction i covers 16 rows x 64 B.
     const half_t* src[PER_WAVE];
     int dst_off[PER_WAVE];
     {
-        const int rsub = lane >> 2;                                   // row within the 16-row group
-        const int chunk = (lane & 3) ^ swz4((lane >> 4) & 3);         // source chunk for LDS position lane&3
+        const int rsub = lane / CPR;                                  // row within the instruction's row group
+        const int pos = lane % CPR;                                   // LDS chunk position within the row
 #pragma unroll
         for (int j = 0; j < PER_WAVE; ++j) {
             const int i = wave * PER_WAVE + j;
-            const int plane = i >> 3, sub = i & 7;
-            const int row = sub * 16 + rsub;
-            const bool isW = (SPLIT == 3) ? (plane >= 2) : (plane >= 1);
-            const bool isLo = (SPLIT == 3) ? (plane & 1) : false;
-            const half_t* base = isW ? (isLo ? Wlo : Whi) : (isLo ? Alo : Ahi);
+            const bool isW = i >= NPA * A_INSTR;
+            const int ii = isW ? i - NPA * A_INSTR : i;
+            const int per = isW ? W_INSTR : A_INSTR;
+            const int plane = ii / per, sub = ii - plane * per;
+            const int row = sub * RPI + rsub;
+            // source chunk for this LDS position (involution; BK=32: 4-chunk rows, BK=64: 8-chunk rows)
+            const int chunk = (BK == 32) ? (pos ^ swz4((row >> 2) & 3)) : (pos ^ ((row >> 1) & 7));
+            const half_t* base = isW ? (plane ? Wlo : Whi) : (plane ? Alo : Ahi);
             const int64_t ld = isW ? g.ldw : g.lda;
             int grow = (isW ? bn : bm) + row;
             const int lim = (isW ? g.N : g.M) - 1;
             grow = grow < lim ? grow : lim;
             src[j] = base + (int64_t)grow * ld + chunk * 8;
-            dst_off[j] = plane * PLANE_BYTES + sub * 1024;
+            dst_off[j] = (isW ? NPA * A_PLANE + plane * W_PLANE : plane * A_PLANE) + sub * 1024;
         }
     }
 
     // ---- fragment read offsets (bytes within a plane)
     const int fr = lane & 15, fq = lane >> 4;
-    const int rswz = (fq ^ swz4((lane >> 2) & 3)) * 16;
-    const int a_off = (wm * 64 + fr) * 64 + rswz;       // + mt*16*64
-    const int w_off = (wn * 64 + fr) * 64 + rswz;       // + nt*16*64
+    const int a_row = (wm * WROWS + fr) * ROWB;         // + mt*16*ROWB
+    const int w_row = (wn * 64 + fr) * ROWB;            // + nt*16*ROWB
+    auto chunk_off = [&](int ks) -> int {               // byte offset of this lane's 16-B chunk of k-step ks
+        return (BK == 32) ? ((fq ^ swz4((fr >> 2) & 3)) * 16) : (((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16);
+    };
 
-    floatx4 acc[4][4];
+    floatx4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
-    // prologue: stage K-tile 0 into buffer 0
+    auto issue = [&](int t, int slot) {
+        if (DBG == 1 && t > 1) return;                       // timing probe: no DMA in the steady state
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) glds16(src[j], smem + dst_off[j]);
-    __syncthreads();                                     // emits vmcnt(0) for the in-flight DMA
-
-    for (int t = 0; t < nk; ++t) {
-        unsigned char* cur = smem + (t & 1) * STAGE;
-        if (t + 1 < nk) {
-            unsigned char* nxt = smem + ((t + 1) & 1) * STAGE;
-#pragma unroll
-            for (int j = 0; j < PER_WAVE; ++j) glds16(src[j] + (int64_t)(t + 1) * BK, nxt + dst_off[j]);
-        }
+        for (int j = 0; j < PER_WAVE; ++j) glds16(src[j] + (int64_t)t * BK, smem + slot * STAGE + dst_off[j]);
+    };
+    auto compute = [&](int slot) {
+        if (DBG == 2) return;                                // timing probe: DMA + barriers only
+        const unsigned char* cur = smem + slot * STAGE;
         const unsigned char* pAhi = cur;
-        const unsigned char* pAlo = cur + PLANE_BYTES;
-        const unsigned char* pWhi = cur + (SPLIT == 3 ? 2 : 1) * PLANE_BYTES;
-        const unsigned char* pWlo = cur + 3 * PLANE_BYTES;
-
-        half8 ah[4], wh[4];
+        const unsigned char* pAlo = cur + A_PLANE;
+        const unsigned char* pWhi = cur + NPA * A_PLANE;
+        const unsigned char* pWlo = pWhi + W_PLANE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ah[i] = *(const half8*)(pAhi + a_off + i * 1024);
-            wh[i] = *(const half8*)(pWhi + w_off + i * 1024);
-        }
-        if (SPLIT == 3) {
-            half8 al[4], wl[4];
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            const int co = chunk_off(ks);
+            half8 wh[4], wl[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                al[i] = *(const half8*)(pAlo + a_off + i * 1024);
-                wl[i] = *(const half8*)(pWlo + w_off + i * 1024);
+                wh[i] = *(const half8*)(pWhi + w_row + i * 16 * ROWB + co);
+                if (SPLIT == 3) wl[i] = *(const half8*)(pWlo + w_row + i * 16 * ROWB + co);
             }
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mh = 0; mh < MT / 4; ++mh) {                   // 4 m-tiles at a time keeps fragments at 64 VGPRs
+                half8 ah[4], al[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *(const half8*)(pAhi + a_row + (mh * 4 + i) * 16 * ROWB + co);
+                    if (SPLIT == 3) al[i] = *(const half8*)(pAlo + a_row + (mh * 4 + i) * 16 * ROWB + co);
                 }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        floatx4 c = acc[mh * 4 + mt][nt];
+                        if (SPLIT == 3) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], c, 0, 0, 0);
+                        }
+                        acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
+                    }
+            }
         }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-        __syncthreads();                                 // next tile landed (vmcnt(0)) and cur fully read
+    };
+
+    if (NSTAGE == 2) {
+        issue(0, 0);
+        __syncthreads();                                     // emits vmcnt(0) for the in-flight DMA
+        for (int t = 0; t < nk; ++t) {
+            if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
+            compute(t & 1);
+            __syncthreads();                                 // next tile landed (vmcnt(0)) and cur fully read
+        }
+    } else {
+        // 3-slot ring: tile t computes from slot t%3 while tiles t+1 and t+2 are in flight / landing.
+        issue(0, 0);
+        if (nk > 1) { issue(1, 1); wait_vmcnt<PER_WAVE>(); } else { wait_vmcnt<0>(); }
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int t = 0; t < nk; ++t) {
+            int s2 = slot + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
+            if (t + 2 < nk) issue(t + 2, s2);                 // slot s2 held tile t-1: all waves left it at the last barrier
+            compute(slot);
+            // tile t+1 must have landed for every wave before anyone reads it; only tile t+2 may stay in flight
+            if (t + 2 < nk) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            slot = slot + 1 == 3 ? 0 : slot + 1;
+        }
     }
 
     // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
@@ -144,9 +199,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
     const bool vec_f32 = ((g.ldo & 3) == 0) && ((g.stride_o & 3) == 0);
     const bool vec_res = ((g.ldr & 3) == 0) && ((g.stride_r & 3) == 0);
     const bool vec_h = ((g.ldoh & 3) == 0) && ((g.stride_oh & 3) == 0);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = bm + wm * 64 + mt * 16 + fr;
+#pragma clang loop unroll(full)
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = bm + wm * WROWS + mt * 16 + fr;
         if (m >= g.M) continue;
         int64_t ps_base = 0;
         if (g.ps_c2 > 0) {
@@ -224,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
 extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (!args || !args->a_hi || !args->w_hi) return CVLM_E_BADARG;
     const cvlm_gemm_args& g = *args;
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK) != 0) return CVLM_E_BADARG;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK_MIN) != 0) return CVLM_E_BADARG;
     if ((g.lda & 7) || (g.ldw & 7) || (g.stride_a & 7) || (g.stride_w & 7)) return CVLM_E_BADARG;
     if (g.split != 1 && g.split != 3) return CVLM_E_BADARG;
     if (g.split == 3 && (!g.a_lo || !g.w_lo)) return CVLM_E_BADARG;
@@ -233,19 +288,54 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     GemmParams p;
     p.a = g;
     if (p.a.batch <= 0) p.a.batch = 1;
-    p.nbx = (g.N + BN - 1) / BN;
-    p.nby = (g.M + BM - 1) / BM;
-    dim3 grid(p.nbx * p.nby, p.a.batch), block(256);
+    static int group_env = -1, variant_env = -1;
+    if (group_env < 0) { const char* e = getenv("CVLM_GEMM_GROUP_M"); group_env = e ? atoi(e) : 8; if (group_env < 1) group_env = 1; }
+    if (variant_env < 0) { const char* e = getenv("CVLM_GEMM_VARIANT"); variant_env = e ? atoi(e) : 0; }
+    p.group_m = group_env;
     hipStream_t s = (hipStream_t)stream;
-    if (g.split == 3) {
-        constexpr int smem = 2 * 4 * PLANE_BYTES;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; }
-        hipLaunchKernelGGL(gemm_nt_kernel<3>, grid, block, smem, s, p);
-    } else {
-        constexpr int smem = 2 * 2 * PLANE_BYTES;
-        hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, smem, s, p);
+    // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
+    int variant = variant_env;
+    if (variant == 0) {
+        // 256x256 tiles (1 workgroup/CU, half the L2->LDS bytes per FLOP) when they fill the 256 CUs well,
+        // otherwise 128x128 tiles (2 workgroups/CU -> 512 slots) for small / skinny problems.
+        const long t5 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * p.a.batch;
+        const long t1 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * p.a.batch;
+        const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
+        const double e1 = (double)t1 / (double)(((t1 + 511) / 512) * 512);
+        variant = (e5 * 1.12 > e1) ? 5 : 1;
     }
+#define CVLM_LAUNCH(SPLIT, WM, WN, NS) CVLM_LAUNCH_D(SPLIT, WM, WN, NS, 32, 0, 4)
+#define CVLM_LAUNCH_D(SPLIT, WM, WN, NS, BKT, DBG, MT)                                                        \
+    do {                                                                                                      \
+        constexpr int NPA_ = (SPLIT == 3) ? 2 : 1;                                                            \
+        constexpr int smem_ = NS * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
+        p.nbx = (g.N + WN * 64 - 1) / (WN * 64);                                                              \
+        p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                            \
+        auto kern_ = gemm_nt_kernel<SPLIT, WM, WN, NS, BKT, DBG, MT>;                                                     \
+        static bool attr_ = false;                                                                            \
+        if (!attr_ && smem_ > 48 * 1024) {                                                                    \
+            (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_); \
+            attr_ = true;                                                                                     \
+        }                                                                                                     \
+        hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby, p.a.batch), dim3(WM* WN * 64), smem_, s, p);             \
+    } while (0)
+    if (g.split == 3) {
+        if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
+        else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
+        else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */
+        else if (variant == 15) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 1, 8);
+        else if (variant == 25) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 2, 8);
+        else if (variant == 3) CVLM_LAUNCH(3, 2, 2, 3);
+        else CVLM_LAUNCH(3, 2, 2, 2);
+    } else {
+        if (variant == 2) CVLM_LAUNCH(1, 4, 2, 3);
+        else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(1, 2, 2, 3, 64, 0, 4);
+        else if (variant == 5) CVLM_LAUNCH_D(1, 2, 4, 3, 32, 0, 8);
+        else if (variant == 3) CVLM_LAUNCH(1, 2, 2, 3);
+        else CVLM_LAUNCH(1, 2, 2, 2);
+    }
+#undef CVLM_LAUNCH
+#undef CVLM_LAUNCH_D
     CVLM_CHECK_LAUNCH();
     return 0;
 }
