@@ -23,6 +23,7 @@
 //
 // Precision: operands are split-half planes; SQK / SPV = 3 issue hi*hi + lo*hi + hi*lo.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/cvlm.h"
 
 namespace {
@@ -356,6 +357,8 @@ int launch_split(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
+int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s);       // attention_g64.hip
+
 extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!args || !args->qkv_hi || !args->out_hi) return CVLM_E_BADARG;
     const cvlm_attn_args& g = *args;
@@ -374,6 +377,9 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!g.relh_hi || !g.relw_hi || (g.split_qk == 3 && (!g.relh_lo || !g.relw_lo))) return CVLM_E_BADARG;
     if (g.grid <= 0 || g.S != g.grid * g.grid) return CVLM_E_BADARG;
     if (g.mode == 1) {
+        static int g64 = -1;
+        if (g64 < 0) { const char* e = getenv("CVLM_ATTN_G64"); g64 = e ? atoi(e) : 1; }
+        if (g64 && g.grid == 64) return cvlm_attention_global64(g, s);        // 1024^2 SAM geometry fast path
         p.L = g.grid; p.LTP = g.grid | 1;
         return launch_split<80, 4, 1, false>(p, s);
     }
