@@ -1,0 +1,173 @@
+"""CPU: host logic -- C-ABI library exports, registry / state_dict contract, geometry, lowpass operator,
+failure without a GPU, sharded text-bank gather over gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import camouflaged_vlm_amd as cv
+from camouflaged_vlm_amd import spec, synth
+
+REPO = cv.REPO_DIR
+
+
+def test_library_exports_every_declared_symbol():
+    from camouflaged_vlm_amd import hip
+    lib = hip.load()
+    hdr = open(os.path.join(REPO, "include", "cvlm.h")).read()
+    declared = set(re.findall(r"\b(cvlm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cvlm_gemm_args", "cvlm_attn_args"}
+    assert len(declared) >= 19
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/cvlm.h but not exported"
+    assert set(hip.EXPORTS) == declared
+    assert lib.cvlm_abi_version() == 1 and lib.cvlm_target_arch() == b"gfx950"
+
+
+def test_bad_arguments_return_error_codes_without_gpu():
+    from camouflaged_vlm_amd import hip
+    import ctypes as C
+    lib = hip.load()
+    assert lib.cvlm_gemm(None, None) == -1
+    g = hip.GemmArgs()
+    g.M = g.N = 16
+    g.K = 20                                            # not a multiple of 32
+    assert lib.cvlm_gemm(C.byref(g), None) == -1
+    assert lib.cvlm_attention(None, None) == -1
+
+
+def test_demo_state_dict_contract():
+    e = spec.full_entries(spec.DEMO_SAM, spec.DEMO_CLIP)
+    assert len(e) == 1195                                # SURVEY.md §8b [measured on the reference]
+    is_buffer = lambda nme: "token_prefix" in nme or "token_suffix" in nme or nme.endswith("gaussian_matrix")
+    n = sum(int(np.prod(s)) if len(s) else 1 for nme, s, _ in e if not is_buffer(nme))
+    assert abs(n / 1e6 - 1039.8) < 0.1                   # parameters (buffers excluded), SURVEY.md §8b
+    names = [x[0] for x in e]
+    assert len(set(names)) == len(names)
+    enc = sum(int(np.prod(s)) for nme, s, _ in e if nme.startswith("image_encoder."))
+    assert abs(enc / 1e6 - 637.21) < 0.05
+    d = dict((nme, s) for nme, s, _ in e)
+    assert d["image_encoder.blocks.7.attn.rel_pos_h"] == (127, 80) and d["image_encoder.blocks.0.attn.rel_pos_h"] == (27, 80)
+    assert d["clip_model.text_encoder.transformer.resblocks.0.attn.in_proj_weight"] == (2304, 768)
+    assert d["clip_model.image_encoder.transformer.resblocks.0.attn.in_proj.weight"] == (3072, 1024)
+
+
+def test_synthetic_weights_are_deterministic_and_order_independent():
+    a = synth.make_tensor("image_encoder.blocks.3.attn.qkv.weight", (480, 160), "linear", 0)
+    b = synth.make_tensor("image_encoder.blocks.3.attn.qkv.weight", (480, 160), "linear", 0)
+    c = synth.make_tensor("image_encoder.blocks.3.attn.qkv.weight", (480, 160), "linear", 1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    i1 = synth.make_inputs(spec.TINY_SAM, spec.TINY_CLIP, 2)[0]
+    i2 = synth.make_inputs(spec.TINY_SAM, spec.TINY_CLIP, 1, index0=1)[0]
+    assert np.array_equal(i1[1], i2[0])                  # image i of a batch == image i generated alone
+
+
+def test_lowpass_operator_equals_fft_highpass():
+    """|x - Re(L x L^T)| == PromptGenerator.fft (image_encoder.py:332-353) for even and non power-of-two N."""
+    from camouflaged_vlm_amd.engine import lowpass_matrices
+    from oracle import cvlm_oracle as O
+    for N in (64, 320):
+        line = int((N * N * 0.25) ** 0.5 // 2)
+        lr, li = lowpass_matrices(N, line)
+        x = torch.randn(2, 3, N, N, dtype=torch.float64)
+        lr, li = lr.double(), li.double()
+        y = (x - (lr @ x @ lr.t() - li @ x @ li.t())).abs()
+        assert float((y - O.fft_highpass(x, 0.25)).abs().max()) < 1e-5
+
+
+def test_registry_and_dropin_state_dict(tmp_path):
+    if cv.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, cv.DROPIN_DIR)
+    import models
+    from cocotrainers.mapleAlphaCLIP import CustomCLIP
+    assert set(models.models.models) >= {"sam", "sam_maskdecoder_edge"}
+    g, c = spec.TINY_SAM, spec.TINY_CLIP
+    enc = dict(patch_size=16, embed_dim=g.embed_dim, depth=g.depth, num_heads=g.num_heads, mlp_ratio=4, out_chans=256,
+               qkv_bias=True, use_rel_pos=True, window_size=14, global_attn_indexes=[1, 3], prompt_embed_dim=256,
+               scale_factor=32, freq_nums=0.25, adaptor="adaptor")           # unused YAML keys are tolerated
+    m = models.make({"name": "sam_maskdecoder_edge", "args": {"inp_size": 320, "loss": "iou", "encoder_mode": enc}})
+    m.load_mapleAlphaCLIP(CustomCLIP(geometry=c))
+    assert set(m.state_dict()) == {n for n, _, _ in spec.full_entries(g, c)}
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_full_state_dict(g, c, seed=3).items()}
+    m.load_state_dict(sd, strict=True)
+    assert torch.equal(m.state_dict()["mask_decoder.iou_token.weight"], sd["mask_decoder.iou_token.weight"])
+    bad = dict(sd)
+    bad.pop("no_mask_embed.weight")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # the product path never falls back
+        m.infer_test(torch.zeros(1, 3, 320, 320), torch.zeros(1, 3, 56, 56), torch.zeros(1, 1, 56, 56))
+    with pytest.raises(AssertionError):
+        m.cuda if False else m.infer_test(torch.zeros(1, 3, 64, 64), None, None)   # wrong image size (image_encoder.py:375)
+    with pytest.raises(NotImplementedError):
+        models.make({"name": "sam", "args": {}})
+
+
+def test_demo_yaml_loads(tmp_path):
+    """configs/demo.yaml of the reference must drive the drop-in unchanged (geometry only, no weights)."""
+    import yaml
+    cfg = yaml.safe_load("""
+model:
+  name: sam_maskdecoder_edge
+  args:
+    inp_size: 1024
+    loss: iou
+    encoder_mode: {name: sam, img_size: 1024, mlp_ratio: 4, patch_size: 16, qkv_bias: true, use_rel_pos: true,
+      window_size: 14, out_chans: 256, scale_factor: 32, input_type: fft, freq_nums: 0.25, prompt_type: highpass,
+      prompt_embed_dim: 256, tuning_stage: 1234, handcrafted_tune: true, embedding_tune: true, adaptor: adaptor,
+      embed_dim: 1280, depth: 32, num_heads: 16, global_attn_indexes: [7, 15, 23, 31]}
+""")
+    g = spec.SamGeometry.from_encoder_mode(cfg["model"]["args"]["inp_size"], cfg["model"]["args"]["encoder_mode"])
+    assert g == spec.DEMO_SAM and g.fft_halfwidth == 256 and g.grid == 64 and g.head_dim == 80
+
+
+def test_eot_lookup():
+    from camouflaged_vlm_amd import host
+    c = host.ovcamo_constants()
+    eot = host.eot_for_classes(c["names_test"].tolist())
+    assert eot[:8] == [10, 7, 8, 7, 7, 8, 8, 7] and len(eot) == 61
+    with pytest.raises(KeyError):
+        host.eot_for_classes(["definitely not a class"])
+
+
+_GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CVLM_REPO"])
+import camouflaged_vlm_amd as cv
+sys.path.insert(0, cv.DROPIN_DIR)
+from cocotrainers.mapleAlphaCLIP import gather_text_features
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+class C: embed_dim = 8
+class FakeEngine:
+    c, device = C, torch.device("cpu")
+    def __init__(self):
+        self.calls = []
+    def text_features(self, eot, split, rows=None):
+        idx = list(range(len(eot)))[rows] if rows is not None else list(range(len(eot)))
+        self.calls.append(len(idx))
+        return torch.tensor([[100.0 * i + j + eot[i] for j in range(8)] for i in idx])
+eng = FakeEngine()
+eot = [7 + (i % 4) for i in range(61)]
+out = gather_text_features(eng, eot, "test")
+ref = FakeEngine().text_features(eot, "test")
+assert out.shape == (61, 8) and torch.equal(out, ref), (rank, out.shape)
+assert eng.calls == [31 if rank == 0 else 30], eng.calls          # each rank encoded only its shard
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_text_bank_sharding_over_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, CVLM_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)

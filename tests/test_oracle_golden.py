@@ -1,0 +1,86 @@
+"""CPU: the oracle (oracle/cvlm_oracle.py) is pinned to golden vectors produced by running the
+REFERENCE itself (tools/make_golden.py).  These tests are what makes the oracle trustworthy as the
+checker of the HIP path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from camouflaged_vlm_amd import spec, synth
+from oracle import cvlm_oracle as O
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with np.load(os.path.join(golden_dir, "tiny_cascade.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def run(gold):
+    g, c = spec.TINY_SAM, spec.TINY_CLIP
+    sd = O.to_torch_sd(synth.make_full_state_dict(g, c))
+    inp, ci, cm = (torch.from_numpy(t) for t in synth.make_inputs(g, c, 2))
+    bank = torch.from_numpy(gold["bank_test"])
+    taps = {}
+    with torch.no_grad():
+        tf = O.clip_text_features(sd, c, gold["eot_test"].tolist())
+        m, pred, logits = O.cascade(inp, ci, cm, sd, g, c, tf, bank, taps)
+    return dict(g=g, c=c, sd=sd, tf=tf, m=m, pred=pred, logits=logits, taps=taps)
+
+
+def d(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+def test_text_encoder_matches_reference(run, gold):
+    assert d(run["tf"], gold["tap_clip_text"]) < 1e-5
+    with torch.no_grad():
+        tr = O.clip_text_features(run["sd"], run["c"], gold["eot_test"].tolist(), truncate=True)
+    assert d(tr, gold["tap_clip_text"]) < 1e-5          # truncation to EOT+1 positions is exact (causal)
+
+
+def test_encoder_stages_match_reference(run, gold):
+    t = run["taps"]
+    assert d(t["patch_embed"][:1], gold["tap_patch_embed"]) < 1e-5
+    assert d(t["highpass"][:1], gold["highpass"]) < 1e-5
+    for i in range(4):
+        assert d(t[f"block{i}"][:1], gold[f"tap_block{i}"]) < 2e-5
+    assert d(t["features"][:1], gold["tap_features"]) < 2e-5
+
+
+def test_decoder_stages_match_reference(run, gold):
+    t = run["taps"]
+    assert d(t["hs"], gold["tap_hs"]) < 2e-5
+    assert d(t["src"].flatten(2).transpose(1, 2), gold["tap_src"]) < 2e-5
+    assert d(t["upscaled"], gold["tap_upscaled"]) < 2e-5
+    assert d(t["low_res_masks"][:1], gold["tap_low_res_masks"]) < 1e-4
+    assert d(O.dense_pe(run["sd"], run["g"].grid)[None], gold["dense_pe"]) < 1e-6
+
+
+def test_cascade_outputs_match_reference(run, gold):
+    assert d(run["m"], gold["mask_logits"]) < 1e-4
+    assert d(run["logits"], gold["class_logits"]) < 1e-4
+    assert d(run["taps"]["pass1_logits"], gold["pass1_logits"]) < 1e-4
+    assert run["pred"].tolist() == gold["pred"].tolist()
+    assert O.mask_iou(run["m"].numpy(), gold["mask_logits"]) >= 0.9999
+
+
+def test_batch_equals_per_image(run):
+    """The reference only runs B=1; the batched oracle must equal per-image calls."""
+    g, c, sd = run["g"], run["c"], run["sd"]
+    inp, ci, cm = (torch.from_numpy(t) for t in synth.make_inputs(g, c, 2))
+    with torch.no_grad():
+        m1, _, l1 = O.cascade(inp[1:], ci[1:], cm[1:], sd, g, c, run["tf"], torch.from_numpy(
+            np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_cascade.npz"))["bank_test"]))
+    assert d(m1, run["m"][1:]) < 1e-5 and d(l1, run["logits"][1:]) < 1e-5
+
+
+def test_tokens_fixture(golden_dir):
+    with np.load(os.path.join(golden_dir, "ovcamo_constants.npz")) as z:
+        tk = z["tokens_test"]
+        assert tk.shape == (61, 77) and z["tokens_train"].shape == (14, 77)
+        # "a photo of a owlfly larva." (measured from the reference tokenizer)
+        assert tk[0, :11].tolist() == [49406, 320, 1125, 539, 320, 34332, 3228, 1592, 1892, 269, 49407]
+        assert z["bank_test"].shape == (61, 768) and abs(float(np.linalg.norm(z["bank_test"][0])) - 1) < 1e-4
