@@ -302,7 +302,19 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         const long t1 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * p.a.batch;
         const double e5 = (double)t5 / (double)(((t5 + 255) / 256) * 256);
         const double e1 = (double)t1 / (double)(((t1 + 511) / 512) * 512);
-        variant = (e5 * 1.12 > e1) ? 5 : 1;
+        // padded work / relative throughput (measured, profiles/r01_gemm_probes.md)
+        const long t2 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * p.a.batch;
+        const double c1 = (double)(((t1 + 511) / 512) * 512) * 1.0;
+        (void)e5; (void)e1;
+        if (t5 >= 200 && t5 <= 256) variant = 5;                                  // one full wave of 256^2 tiles
+        else if (t5 >= 1536) {
+            const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / 1.08;
+            const double c5 = (double)(((t5 + 255) / 256) * 256) * 4.0 / 1.20;
+            variant = (c5 <= c2 && c5 <= c1) ? 5 : (c2 <= c1 ? 2 : 1);
+        } else {
+            const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0;
+            variant = (c2 < c1) ? 2 : 1;
+        }
     }
 #define CVLM_LAUNCH(SPLIT, WM, WN, NS) CVLM_LAUNCH_D(SPLIT, WM, WN, NS, 32, 0, 4)
 #define CVLM_LAUNCH_D(SPLIT, WM, WN, NS, BKT, DBG, MT)                                                        \
