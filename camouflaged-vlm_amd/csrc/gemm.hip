@@ -129,13 +129,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 #pragma unroll
         for (int j = 0; j < PER_WAVE; ++j) glds16(src[j] + (int64_t)t * BK, smem + slot * STAGE + dst_off[j]);
     };
-    auto compute = [&](int slot) {
-        if (DBG == 2) return;                                // timing probe: DMA + barriers only
+    // One K-tile of MFMAs from `slot`; the DMA of K-tile `tn` into `sn` (tn < 0: none) is issued in pieces
+    // between the MFMA groups so the load issue (readfirstlane + m0 + TA acceptance, ~100 cycles each)
+    // hides in the matrix pipe's shadow instead of stalling all waves right after the barrier.
+    constexpr int NG = (BK / 32) * MT;                               // MFMA groups (one per (k-step, m-tile))
+    auto compute = [&](int slot, int tn, int sn) {
+        if (DBG == 2) {
+            if (tn >= 0) issue(tn, sn);
+            return;
+        }
         const unsigned char* cur = smem + slot * STAGE;
         const unsigned char* pAhi = cur;
         const unsigned char* pAlo = cur + A_PLANE;
         const unsigned char* pWhi = cur + NPA * A_PLANE;
         const unsigned char* pWlo = pWhi + W_PLANE;
+        const bool dma = tn >= 0 && !(DBG == 1 && tn > 1);
+        const int64_t koff = (int64_t)tn * BK;
+        unsigned char* nxt = smem + sn * STAGE;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             const int co = chunk_off(ks);
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     if (SPLIT == 3) al[i] = *(const half8*)(pAlo + a_row + (mh * 4 + i) * 16 * ROWB + co);
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         floatx4 c = acc[mh * 4 + mt][nt];
@@ -164,6 +174,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         }
                         acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
                     }
+                    const int gidx = (ks * (MT / 4) + mh) * 4 + mt;
+                    const int j0 = (gidx * PER_WAVE) / NG, j1 = ((gidx + 1) * PER_WAVE) / NG;
+                    if (dma) {
+#pragma unroll
+                        for (int j = j0; j < j1; ++j) glds16(src[j] + koff, nxt + dst_off[j]);
+                    }
+                }
             }
         }
     };
@@ -172,8 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         issue(0, 0);
         __syncthreads();                                     // emits vmcnt(0) for the in-flight DMA
         for (int t = 0; t < nk; ++t) {
-            if (t + 1 < nk) issue(t + 1, (t + 1) & 1);
-            compute(t & 1);
+            compute(t & 1, t + 1 < nk ? t + 1 : -1, (t + 1) & 1);
             __syncthreads();                                 // next tile landed (vmcnt(0)) and cur fully read
         }
     } else {
@@ -184,8 +200,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         int slot = 0;
         for (int t = 0; t < nk; ++t) {
             int s2 = slot + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
-            if (t + 2 < nk) issue(t + 2, s2);                 // slot s2 held tile t-1: all waves left it at the last barrier
-            compute(slot);
+            // slot s2 held tile t-1: all waves left it at the last barrier
+            compute(slot, t + 2 < nk ? t + 2 : -1, s2);
             // tile t+1 must have landed for every wave before anyone reads it; only tile t+2 may stay in flight
             if (t + 2 < nk) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
