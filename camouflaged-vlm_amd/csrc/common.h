@@ -51,10 +51,25 @@ __device__ __forceinline__ float wave_max(float v) {
 // activation codes shared by the GEMM epilogue and the row kernels
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3, ACT_ABS_POST = 4 };
 
+// erf, branch-free (Abramowitz & Stegun 7.1.26, |abs err| <= 1.5e-7 -- fp32-grade for the exact-erf GELU
+// of common.py:13-26; the library erff is ~4x the instructions and divergent, and cost 25 % of the
+// lin1 GEMM when it ran in the epilogue).
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float r = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
-        case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact-erf GELU
-        case ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));                   // x*sigmoid(1.702x)
+        case ACT_GELU: return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); // exact-erf GELU
+        case ACT_QUICKGELU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v)); // x*sigmoid(1.702x)
         case ACT_RELU: return fmaxf(v, 0.0f);
         default: return v;
     }

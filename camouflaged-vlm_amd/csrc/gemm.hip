@@ -175,7 +175,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
                     }
                     const int gidx = (ks * (MT / 4) + mh) * 4 + mt;
-                    const int j0 = (gidx * PER_WAVE) / NG, j1 = ((gidx + 1) * PER_WAVE) / NG;
+                    // DMA pieces go out during the first half of the MFMA groups: the last piece then has half a
+                    // K-tile of MFMA time to land before the end-of-tile wait
+                    constexpr int NGI = (NSTAGE == 2 && NG >= 2) ? NG / 2 : NG;
+                    const int g0 = gidx < NGI ? gidx : NGI, g1 = gidx + 1 < NGI ? gidx + 1 : NGI;
+                    const int j0 = (g0 * PER_WAVE) / NGI, j1 = (g1 * PER_WAVE) / NGI;
                     if (dma) {
 #pragma unroll
                         for (int j = j0; j < j1; ++j) glds16(src[j] + koff, nxt + dst_off[j]);
@@ -328,7 +332,8 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             const double c5 = (double)(((t5 + 255) / 256) * 256) * 4.0 / 1.20;
             variant = (c5 <= c2 && c5 <= c1) ? 5 : (c2 <= c1 ? 2 : 1);
         } else {
-            const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0;
+            // mid-size grids: 256x128 pays off on the long-M SAM shapes, 128^2 on the short CLIP ones
+            const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / (g.M >= 16384 ? 1.08 : 0.97);
             variant = (c2 < c1) ? 2 : 1;
         }
     }
