@@ -196,6 +196,65 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             compute(t & 1, t + 1 < nk ? t + 1 : -1, (t + 1) & 1);
             __syncthreads();                                 // next tile landed (vmcnt(0)) and cur fully read
         }
+    } else if (NSTAGE == 4) {
+        // Two slots with mid-tile recycling (MT = 8, BK = 32): all fragments of tile t are pulled into
+        // registers at the top of the iteration, a barrier then frees slot t&1 and the DMA of tile t+2
+        // streams into it underneath the 96 MFMAs of tile t.  Each DMA has ~1.5 iterations to land and
+        // the memory pipe never drains: s_waitcnt vmcnt is counted (never 0 in steady state) and the
+        // barriers are raw s_barrier (guide §5 "Pipelining across barriers").
+        issue(0, 0);
+        if (nk > 1) { issue(1, 1); wait_vmcnt<PER_WAVE>(); } else { wait_vmcnt<0>(); }
+        __builtin_amdgcn_s_barrier();
+        const int co = chunk_off(0);
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* cur = smem + (t & 1) * STAGE;
+            const unsigned char* pAhi = cur;
+            const unsigned char* pAlo = cur + A_PLANE;
+            const unsigned char* pWhi = cur + NPA * A_PLANE;
+            const unsigned char* pWlo = pWhi + W_PLANE;
+            half8 wh[4], wl[4], ah[MT], al[MT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wh[i] = *(const half8*)(pWhi + w_row + i * 16 * ROWB + co);
+                if (SPLIT == 3) wl[i] = *(const half8*)(pWlo + w_row + i * 16 * ROWB + co);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = *(const half8*)(pAhi + a_row + i * 16 * ROWB + co);
+                if (SPLIT == 3) al[i] = *(const half8*)(pAlo + a_row + i * 16 * ROWB + co);
+            }
+            const bool dma = (t + 2 < nk) && DBG != 1;
+            const int64_t koff = (int64_t)(t + 2) * BK;
+            unsigned char* nxt = smem + (t & 1) * STAGE;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (DBG != 2) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        floatx4 c = acc[mt][nt];
+                        if (SPLIT == 3) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], c, 0, 0, 0);
+                        }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
+                    }
+                }
+                if (mt == 0) {
+                    // every fragment of tile t is in registers: slot t&1 may be overwritten once ALL waves are here
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (dma && mt >= 1 && mt <= 4) {
+                    constexpr int PP = PER_WAVE / 4;
+#pragma unroll
+                    for (int j = (mt - 1) * PP; j < (mt == 4 ? PER_WAVE : mt * PP); ++j)
+                        glds16(src[j] + koff, nxt + dst_off[j]);
+                }
+            }
+            // tile t+1 (issued one iteration ago) must have landed for every wave; tile t+2 may stay in flight
+            if (dma) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
     } else {
         // 3-slot ring: tile t computes from slot t%3 while tiles t+1 and t+2 are in flight / landing.
         issue(0, 0);
@@ -341,7 +400,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #define CVLM_LAUNCH_D(SPLIT, WM, WN, NS, BKT, DBG, MT)                                                        \
     do {                                                                                                      \
         constexpr int NPA_ = (SPLIT == 3) ? 2 : 1;                                                            \
-        constexpr int smem_ = NS * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
+        constexpr int smem_ = (NS == 4 ? 2 : NS) * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
         p.nbx = (g.N + WN * 64 - 1) / (WN * 64);                                                              \
         p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                            \
         auto kern_ = gemm_nt_kernel<SPLIT, WM, WN, NS, BKT, DBG, MT>;                                                     \
@@ -356,6 +415,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
         else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
         else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */
+        else if (variant == 6) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 0, 8);          /* same tile, mid-tile slot recycling */
+        else if (variant == 16) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 1, 8);
+        else if (variant == 26) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 2, 8);
         else if (variant == 15) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 1, 8);
         else if (variant == 25) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 2, 8);
         else if (variant == 3) CVLM_LAUNCH(3, 2, 2, 3);
