@@ -358,6 +358,7 @@ int launch_split(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s);       // attention_g64.hip
+int cvlm_attention_window14(const cvlm_attn_args& g, hipStream_t s);       // attention_win.hip
 
 extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!args || !args->qkv_hi || !args->out_hi) return CVLM_E_BADARG;
@@ -385,6 +386,9 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     }
     if (g.mode == 2) {
         if (g.window <= 0 || !g.pad_hi || ((g.split_qk == 3 || g.split_pv == 3) && !g.pad_lo)) return CVLM_E_BADARG;
+        static int w14 = -1;
+        if (w14 < 0) { const char* e = getenv("CVLM_ATTN_W14"); w14 = e ? atoi(e) : 1; }
+        if (w14 && g.window == 14) return cvlm_attention_window14(g, s);      // SAM window geometry fast path
         p.L = g.window; p.LTP = g.window | 1;
         p.nwx = (g.grid + g.window - 1) / g.window;
         p.S_seq = g.window * g.window;

@@ -1,0 +1,322 @@
+// ViT-H *window* attention (14x14 windows, head_dim 80) with decomposed rel-pos bias
+// (image_encoder.py:488-504, 507-553, 589-625; 28 of the 32 SAM blocks).
+//
+// Two workgroups of 4 waves x 32 queries (128 + 68 of the 196 queries; 2 workgroups/CU at <= 256 VGPRs)
+// per (image, window, head); K/V of the whole window
+// stream through LDS in seven 32-slot tiles as in attention.hip (query on the lane for S^T and O^T,
+// pad tokens = qkv bias rows, not stored).  What differs is the bias: instead of gathering
+// Th[q][kh] + Tw[q][kw] per score element (index math + two LDS reads per element made the generic
+// kernel VALU-bound), the bias is folded into the QK^T contraction:
+//     Q_aug = [ q (80) | Th[q][0..13]/scale | Tw[q][0..13]/scale | 0 0 0 0 ]      (112 = 7 k-steps of 16)
+//     K_aug = [ k (80) | onehot14(kh)       | onehot14(kw)       | 0 0 0 0 ]
+// so S^T = K_aug . Q_aug^T already contains (q.k + bias/scale).  The one-hot block is the same for every
+// window and head (a 224 x 32 constant in LDS); Th/Tw are formed once per workgroup with MFMA
+// (U = Q . R^T, 27 table rows) and kept as two extra split-half B fragments per lane.
+#include "common.h"
+#include "../../include/cvlm.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
+    typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
+    fp16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4*)p);
+    return __builtin_bit_cast(half4, r);
+}
+
+template <int SQK, int SPV>
+__global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args g, const int nwx) {
+    constexpr int HD = 80, KS = 5, ND = 3, CPR = 10, KP = 88, VP = 96, NT = 256, L = 14, S_SEQ = 196;
+    constexpr int OP = 40;                                    // one-hot row pitch (halves): 5 chunks, odd
+    constexpr int NPL = (SQK == 3 || SPV == 3) ? 2 : 1;
+    constexpr int KT = 32, NKT = 7;                           // 7 x 32 = 224 >= 196 key slots
+    constexpr int KPLANE = KT * KP, VPLANE = KT * VP;
+    constexpr int UNITS = 2 * NPL * KT * CPR;
+    constexpr int UPT = (UNITS + NT - 1) / NT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    half_t* Ks = (half_t*)smem;                               // [NPL][KT][KP]
+    half_t* Vs = Ks + NPL * KPLANE;                           // [NPL][KT][VP]
+    constexpr int KVB = NPL * (KPLANE + VPLANE) * 2 + 128;    // K/V bytes (+ slack for the padded d tile)
+    constexpr int REGION = KVB > 128 * 33 * 4 ? KVB : 128 * 33 * 4;
+    half_t* OH = (half_t*)(smem + REGION);                    // [224][OP] one-hot(kh) | one-hot(kw)
+    int* rowoff = (int*)(OH + 224 * OP);                      // [KT]
+    float* Taug = (float*)smem;                               // prologue only, aliases K/V: [128][33]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qc = lane & 31, half = lane >> 5;
+    const int head = blockIdx.y, seq = blockIdx.z;
+    const int D = g.heads * HD;
+    const int64_t ld = 3 * (int64_t)D;
+    const half_t* qkv_hi = (const half_t*)g.qkv_hi;
+    const half_t* qkv_lo = (const half_t*)g.qkv_lo;
+    const half_t* pad_hi = (const half_t*)g.pad_hi;
+    const half_t* pad_lo = (const half_t*)g.pad_lo;
+    const int nwin = nwx * nwx;
+    const int b = seq / nwin, w = seq - b * nwin;
+    const int wy = w / nwx, wx = w - wy * nwx;
+    auto token_of = [&](int slot) -> int {
+        const int iy = slot / L, ix = slot - iy * L;
+        const int y = wy * L + iy, x = wx * L + ix;
+        if (y >= g.grid || x >= g.grid) return -1;
+        return (b * g.grid + y) * g.grid + x;
+    };
+
+    // ---- constant one-hot block of K_aug
+    for (int i = tid; i < 224 * 32; i += NT) {
+        const int slot = i >> 5, c = i & 31;
+        const int kh = slot / L, kw = slot - kh * L;
+        OH[slot * OP + c] = (half_t)((slot < S_SEQ && (c == kh || c == 14 + kw)) ? 1.0f : 0.0f);
+    }
+
+    // ---- queries
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bool wave_active = q0 < S_SEQ;                      // wave-uniform
+    const int qslot = q0 + qc;
+    const bool qvalid = qslot < S_SEQ;
+    const int qs = qvalid ? qslot : S_SEQ - 1;
+    const int qtok = token_of(qs);
+    half8 qh[KS + 2], ql[KS + 2];
+    {
+        const half_t* bh = qtok < 0 ? pad_hi : qkv_hi + (int64_t)qtok * ld;
+        const half_t* bl = qtok < 0 ? pad_lo : qkv_lo + (int64_t)qtok * ld;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qh[ks] = *(const half8*)(bh + head * HD + 16 * ks + 8 * half);
+            if (SQK == 3) ql[ks] = *(const half8*)(bl + head * HD + 16 * ks + 8 * half);
+        }
+    }
+    // ---- Th / Tw for this query: U = Q . R^T (27 rows -> one 32-row MFMA tile per table), scattered to Taug[q][..]
+    {
+        const int qhh = qs / L, qww = qs - qhh * L;
+        float* Tq = Taug + (wave * 32 + qc) * 33;
+        if (half == 0) { Tq[28] = 0.f; Tq[29] = 0.f; Tq[30] = 0.f; Tq[31] = 0.f; }
+#pragma unroll 1
+        for (int tb = 0; tb < 2; ++tb) {
+            const half_t* Rhi = (const half_t*)(tb ? g.relw_hi : g.relh_hi);
+            const half_t* Rlo = (const half_t*)(tb ? g.relw_lo : g.relh_lo);
+            const int cq = tb ? qww : qhh;
+            floatx16 u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = 0.f;
+            const int rr = qc < 27 ? qc : 26;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 ah = *(const half8*)(Rhi + rr * HD + 16 * ks + 8 * half);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], u, 0, 0, 0);
+                if (SQK == 3) {
+                    const half8 al = *(const half8*)(Rlo + rr * HD + 16 * ks + 8 * half);
+                    u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], u, 0, 0, 0);
+                    u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], u, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int kidx = cq + L - 1 - j;
+                if (j < 27 && kidx >= 0 && kidx < L) Tq[tb * 14 + kidx] = u[r];
+            }
+        }
+    }
+    __syncthreads();
+    {
+        // augmented B fragments: k-step 5 covers aug dims 0..15, k-step 6 dims 16..31; lane holds dims 8*half .. +8
+        const float inv_scale = 1.0f / g.scale;
+        const float* Tq = Taug + (wave * 32 + qc) * 33;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                half_t h, l;
+                split_h2(Tq[16 * a + 8 * half + j] * inv_scale, h, l);
+                qh[KS + a][j] = h;
+                ql[KS + a][j] = (SQK == 3) ? l : (half_t)0.f;
+            }
+    }
+    __syncthreads();                                          // Taug (aliasing K/V) is dead from here on
+
+    // ---- K/V staging
+    half8 stage[UPT];
+    auto row_token = [&](int t, int row) -> int {
+        int slot = t * KT + row;
+        slot = slot < S_SEQ ? slot : S_SEQ - 1;
+        return token_of(slot);
+    };
+    auto prefetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            const int u = tid + i * NT;
+            if (u < UNITS) {
+                const int chunk = u % CPR;
+                const int row = (u / CPR) % KT;
+                const int po = u / (CPR * KT);
+                const int op = po / NPL, pl = po - op * NPL;
+                const int tok = rowoff[row];
+                const half_t* base = tok < 0 ? (pl ? pad_lo : pad_hi) : (pl ? qkv_lo : qkv_hi) + (int64_t)tok * ld;
+                stage[i] = *(const half8*)(base + (op + 1) * D + head * HD + chunk * 8);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < UPT; ++i) {
+            const int u = tid + i * NT;
+            if (u < UNITS) {
+                const int chunk = u % CPR;
+                const int row = (u / CPR) % KT;
+                const int po = u / (CPR * KT);
+                const int op = po / NPL, pl = po - op * NPL;
+                half_t* dst = op ? Vs + pl * VPLANE + row * VP : Ks + pl * KPLANE + row * KP;
+                *(half8*)(dst + chunk * 8) = stage[i];
+            }
+        }
+    };
+    if (tid < KT) rowoff[tid] = row_token(0, tid);
+    __syncthreads();
+    prefetch();
+
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx16 o[ND];
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    const float scale = g.scale;
+    const int tg = lane >> 4, ti = lane & 15;
+    const int v_lane_off = (4 * (tg >> 1) + (ti >> 2)) * VP + 16 * (tg & 1) + 4 * (ti & 3);
+
+#pragma unroll 1
+    for (int t = 0; t < NKT; ++t) {
+        commit();
+        if (t + 1 < NKT && tid < KT) rowoff[tid] = row_token(t + 1, tid);
+        __syncthreads();
+        if (t + 1 < NKT) prefetch();
+        if (wave_active) {
+            const int sub = 0;
+            floatx16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const half_t* kr = Ks + (sub * 32 + qc) * KP + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 kh = *(const half8*)(kr + 16 * ks);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+                if (SQK == 3) {
+                    const half8 kl = *(const half8*)(kr + KPLANE + 16 * ks);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+                }
+            }
+            const half_t* ohr = OH + (t * KT + sub * 32 + qc) * OP + 8 * half;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {                     // bias: exact one-hot rows x (T/scale) hi (+ lo)
+                const half8 oh8 = *(const half8*)(ohr + 16 * a);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, qh[KS + a], s, 0, 0, 0);
+                if (SQK == 3) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, ql[KS + a], s, 0, 0, 0);
+            }
+            const int b0 = t * KT + sub * 32 + 4 * half;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int slot = b0 + (r & 3) + 8 * (r >> 2);
+                const float v = (slot < S_SEQ) ? s[r] * scale : -INFINITY;
+                s[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f((m_run - m_new) * LOG2E);
+            const float mneg = m_new * LOG2E;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(s[r] * LOG2E - mneg);
+                s[r] = e;
+                ps += e;
+            }
+            l_run = l_run * alpha + ps;
+            if (!__all(m_new == m_run)) {
+#pragma unroll
+                for (int n = 0; n < ND; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            }
+            m_run = m_new;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                half8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    half_t eh, el;
+                    split_h2(s[8 * k2 + j], eh, el);
+                    ph[j] = eh;
+                    if (SPV == 3) pl[j] = el;
+                }
+                const half_t* vb = Vs + (sub * 32 + 16 * k2) * VP + v_lane_off;
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    const half4 v0 = lds_read_tr16(vb + 32 * n);
+                    const half4 v1 = lds_read_tr16(vb + 32 * n + 8 * VP);
+                    const half8 vh = half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[n], 0, 0, 0);
+                    if (SPV == 3) {
+                        const half4 w0 = lds_read_tr16(vb + VPLANE + 32 * n);
+                        const half4 w1 = lds_read_tr16(vb + VPLANE + 32 * n + 8 * VP);
+                        const half8 vl = half8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                        o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[n], 0, 0, 0);
+                        o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (wave_active && qvalid && qtok >= 0) {
+        const float inv = 1.0f / l_tot;
+        half_t* oh = (half_t*)g.out_hi + (int64_t)qtok * D + head * HD;
+        half_t* ol = g.out_lo ? (half_t*)g.out_lo + (int64_t)qtok * D + head * HD : nullptr;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = 32 * n + 8 * rg + 4 * half;
+                if (d < HD) {
+                    half_t h[4], l4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) split_h2(o[n][4 * rg + j] * inv, h[j], l4[j]);
+                    *(half4*)(oh + d) = half4{h[0], h[1], h[2], h[3]};
+                    if (ol) *(half4*)(ol + d) = half4{l4[0], l4[1], l4[2], l4[3]};
+                }
+            }
+    }
+}
+
+template <int SQK, int SPV>
+int launch_win(const cvlm_attn_args& g, hipStream_t s) {
+    constexpr int NPL = (SQK == 3 || SPV == 3) ? 2 : 1;
+    constexpr int kv = NPL * 32 * (88 + 96) * 2 + 128;
+    constexpr int smem = (kv > 128 * 33 * 4 ? kv : 128 * 33 * 4) + 224 * 40 * 2 + 32 * 4;
+    const int nwx = (g.grid + 13) / 14;
+    auto kern = attn_win14_kernel<SQK, SPV>;
+    static bool attr = false;
+    if (!attr && smem > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(2, g.heads, g.B * nwx * nwx), dim3(256), smem, s, g, nwx);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+// called from cvlm_attention() for mode 2, window 14, head_dim 80
+int cvlm_attention_window14(const cvlm_attn_args& g, hipStream_t s) {
+    if (g.split_qk == 3 && g.split_pv == 3) return launch_win<3, 3>(g, s);
+    if (g.split_qk == 3 && g.split_pv == 1) return launch_win<3, 1>(g, s);
+    if (g.split_qk == 1 && g.split_pv == 1) return launch_win<1, 1>(g, s);
+    return CVLM_E_UNSUPPORTED;
+}
