@@ -69,11 +69,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     const int qc = lane & 31, half = lane >> 5;
     const int head = blockIdx.y, seq = blockIdx.z;
     const int S_seq = p.S_seq, L = p.L, D = p.D;
-    const int64_t ld = 3 * (int64_t)D;
     const half_t* qkv_hi = (const half_t*)g.qkv_hi;
     const half_t* qkv_lo = (const half_t*)g.qkv_lo;
     const half_t* pad_hi = (const half_t*)g.pad_hi;
     const half_t* pad_lo = (const half_t*)g.pad_lo;
+    const int64_t qkv_plane = qkv_lo - qkv_hi, pad_plane = pad_lo - pad_hi;   // lo-plane displacement (elements)
 
     int b = seq, wy = 0, wx = 0;
     if (MODE == 2) {
@@ -82,16 +82,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
         const int w = seq - b * nwin;
         wy = w / p.nwx; wx = w - wy * p.nwx;
     }
-    // token index of a slot of this sequence, or -1 for a window pad token
+    // token index (within image b) of a slot of this sequence, or -1 for a window pad token
     auto token_of = [&](int slot) -> int {
         if (MODE == 2) {
             const int iy = slot / g.window, ix = slot - iy * g.window;
             const int y = wy * g.window + iy, x = wx * g.window + ix;
             if (y >= g.grid || x >= g.grid) return -1;
-            return (b * g.grid + y) * g.grid + x;
+            return y * g.grid + x;
         }
-        return b * g.S + slot;
+        return slot;
     };
+    const QkvStrides QS = qkv_strides(g.qkv_layout, g.S, g.B, g.heads, HD);
 
     // ---------------- queries: one per lane (lane & 31), fragments straight from global memory
     const int q0 = blockIdx.x * (NW * 32) + wave * 32;
@@ -102,12 +103,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     const int qtok = token_of(qs);
     half8 qh[KS], ql[KS];
     {
-        const half_t* bh = qtok < 0 ? pad_hi : qkv_hi + (int64_t)qtok * ld;
-        const half_t* bl = qtok < 0 ? pad_lo : qkv_lo + (int64_t)qtok * ld;
+        const int64_t qo = qtok < 0 ? (int64_t)head * HD : qkv_offset(QS, b, qtok, 0, head);
+        const half_t* bh = (qtok < 0 ? pad_hi : qkv_hi) + qo;
+        const half_t* bl = bh + (qtok < 0 ? pad_plane : qkv_plane);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qh[ks] = *(const half8*)(bh + head * HD + 16 * ks + 8 * half);
-            if (SQK == 3) ql[ks] = *(const half8*)(bl + head * HD + 16 * ks + 8 * half);
+            qh[ks] = *(const half8*)(bh + 16 * ks + 8 * half);
+            if (SQK == 3) ql[ks] = *(const half8*)(bl + 16 * ks + 8 * half);
         }
     }
 
@@ -166,8 +168,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                 const int po = u / (CPR * 64);             // (operand, plane)
                 const int op = po / NPL, pl = po - op * NPL;
                 const int tok = (MODE == 2) ? rowoff[row] : row_token(t, row);
-                const half_t* base = tok < 0 ? (pl ? pad_lo : pad_hi) : (pl ? qkv_lo : qkv_hi) + (int64_t)tok * ld;
-                stage[i] = *(const half8*)(base + (op + 1) * D + head * HD + chunk * 8);
+                const int64_t ro = tok < 0 ? (int64_t)(op + 1) * D + head * HD
+                                           : qkv_offset(QS, b, tok, op + 1, head);
+                // plane / pad selection by integer arithmetic (a 4-way pointer select was turned into a
+                // stack lookup table by the compiler, i.e. scratch traffic in the staging loop)
+                const int64_t po_ = tok < 0 ? pad_plane * pl : qkv_plane * pl;
+                const half_t* base = (tok < 0 ? pad_hi : qkv_hi) + po_ + ro;
+                stage[i] = *(const half8*)(base + chunk * 8);
             }
         }
     };
@@ -311,8 +318,9 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (wave_active && qvalid && qtok >= 0) {
         const float inv = 1.0f / l_tot;
-        half_t* oh = (half_t*)g.out_hi + (int64_t)qtok * D + head * HD;
-        half_t* ol = g.out_lo ? (half_t*)g.out_lo + (int64_t)qtok * D + head * HD : nullptr;
+        const int64_t orow = ((int64_t)b * g.S + qtok) * D + head * HD;
+        half_t* oh = (half_t*)g.out_hi + orow;
+        half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
 #pragma unroll
         for (int n = 0; n < ND; ++n)
 #pragma unroll

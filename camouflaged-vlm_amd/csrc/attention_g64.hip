@@ -38,16 +38,17 @@ __global__ __launch_bounds__(256, 2) void attn_g64_kernel(const cvlm_attn_args g
     const int qc = lane & 31, half = lane >> 5;
     const int head = blockIdx.y, b = blockIdx.z;
     const int D = g.heads * HD;
-    const int64_t ld = 3 * (int64_t)D;
-    const half_t* qkv_hi = (const half_t*)g.qkv_hi + (int64_t)b * S * ld;
-    const half_t* qkv_lo = (const half_t*)g.qkv_lo + (int64_t)b * S * ld;
+    const half_t* qkv_hi = (const half_t*)g.qkv_hi;
+    const half_t* qkv_lo = (const half_t*)g.qkv_lo;
+    const QkvStrides QS = qkv_strides(g.qkv_layout, S, g.B, g.heads, HD);
 
     const int qslot = blockIdx.x * 128 + wave * 32 + qc;     // 4096 % 128 == 0: every query is valid
     half8 qh[KS], ql[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        qh[ks] = *(const half8*)(qkv_hi + (int64_t)qslot * ld + head * HD + 16 * ks + 8 * half);
-        if (SQK == 3) ql[ks] = *(const half8*)(qkv_lo + (int64_t)qslot * ld + head * HD + 16 * ks + 8 * half);
+        const int64_t qo = qkv_offset(QS, b, qslot, 0, head);
+        qh[ks] = *(const half8*)(qkv_hi + qo + 16 * ks + 8 * half);
+        if (SQK == 3) ql[ks] = *(const half8*)(qkv_lo + qo + 16 * ks + 8 * half);
     }
     const int qhh = qslot >> 6, qww = qslot & 63;
     float* Tq = T + (wave * 32 + qc) * LTP;
@@ -102,8 +103,8 @@ __global__ __launch_bounds__(256, 2) void attn_g64_kernel(const cvlm_attn_args g
                 const int row = (u / CPR) % KT;
                 const int po = u / (CPR * KT);
                 const int op = po / NPL, pl = po - op * NPL;
-                const half_t* base = (pl ? qkv_lo : qkv_hi) + (int64_t)(t * KT + row) * ld;
-                stage[i] = *(const half8*)(base + (op + 1) * D + head * HD + chunk * 8);
+                const half_t* base = (pl ? qkv_lo : qkv_hi) + qkv_offset(QS, b, t * KT + row, op + 1, head);
+                stage[i] = *(const half8*)(base + chunk * 8);
             }
         }
     };

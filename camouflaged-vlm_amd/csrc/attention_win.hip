@@ -48,11 +48,11 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     const int qc = lane & 31, half = lane >> 5;
     const int head = blockIdx.y, seq = blockIdx.z;
     const int D = g.heads * HD;
-    const int64_t ld = 3 * (int64_t)D;
     const half_t* qkv_hi = (const half_t*)g.qkv_hi;
     const half_t* qkv_lo = (const half_t*)g.qkv_lo;
     const half_t* pad_hi = (const half_t*)g.pad_hi;
     const half_t* pad_lo = (const half_t*)g.pad_lo;
+    const int64_t qkv_plane = qkv_lo - qkv_hi, pad_plane = pad_lo - pad_hi;   // lo-plane displacement (elements)
     const int nwin = nwx * nwx;
     const int b = seq / nwin, w = seq - b * nwin;
     const int wy = w / nwx, wx = w - wy * nwx;
@@ -60,8 +60,10 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
         const int iy = slot / L, ix = slot - iy * L;
         const int y = wy * L + iy, x = wx * L + ix;
         if (y >= g.grid || x >= g.grid) return -1;
-        return (b * g.grid + y) * g.grid + x;
+        return y * g.grid + x;
     };
+    const int SI = g.grid * g.grid;
+    const QkvStrides QS = qkv_strides(g.qkv_layout, SI, g.B, g.heads, HD);
 
     // ---- constant one-hot block of K_aug
     for (int i = tid; i < 224 * 32; i += NT) {
@@ -79,12 +81,13 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     const int qtok = token_of(qs);
     half8 qh[KS + 2], ql[KS + 2];
     {
-        const half_t* bh = qtok < 0 ? pad_hi : qkv_hi + (int64_t)qtok * ld;
-        const half_t* bl = qtok < 0 ? pad_lo : qkv_lo + (int64_t)qtok * ld;
+        const int64_t qo = qtok < 0 ? (int64_t)head * HD : qkv_offset(QS, b, qtok, 0, head);
+        const half_t* bh = (qtok < 0 ? pad_hi : qkv_hi) + qo;
+        const half_t* bl = bh + (qtok < 0 ? pad_plane : qkv_plane);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qh[ks] = *(const half8*)(bh + head * HD + 16 * ks + 8 * half);
-            if (SQK == 3) ql[ks] = *(const half8*)(bl + head * HD + 16 * ks + 8 * half);
+            qh[ks] = *(const half8*)(bh + 16 * ks + 8 * half);
+            if (SQK == 3) ql[ks] = *(const half8*)(bl + 16 * ks + 8 * half);
         }
     }
     // ---- Th / Tw for this query: U = Q . R^T (27 rows -> one 32-row MFMA tile per table), scattered to Taug[q][..]
@@ -153,8 +156,13 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
                 const int po = u / (CPR * KT);
                 const int op = po / NPL, pl = po - op * NPL;
                 const int tok = rowoff[row];
-                const half_t* base = tok < 0 ? (pl ? pad_lo : pad_hi) : (pl ? qkv_lo : qkv_hi) + (int64_t)tok * ld;
-                stage[i] = *(const half8*)(base + (op + 1) * D + head * HD + chunk * 8);
+                const int64_t ro = tok < 0 ? (int64_t)(op + 1) * D + head * HD
+                                           : qkv_offset(QS, b, tok, op + 1, head);
+                // plane / pad selection by integer arithmetic (a 4-way pointer select was turned into a
+                // stack lookup table by the compiler, i.e. scratch traffic in the staging loop)
+                const int64_t po_ = tok < 0 ? pad_plane * pl : qkv_plane * pl;
+                const half_t* base = (tok < 0 ? pad_hi : qkv_hi) + po_ + ro;
+                stage[i] = *(const half8*)(base + chunk * 8);
             }
         }
     };
@@ -276,8 +284,9 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (wave_active && qvalid && qtok >= 0) {
         const float inv = 1.0f / l_tot;
-        half_t* oh = (half_t*)g.out_hi + (int64_t)qtok * D + head * HD;
-        half_t* ol = g.out_lo ? (half_t*)g.out_lo + (int64_t)qtok * D + head * HD : nullptr;
+        const int64_t orow = ((int64_t)b * SI + qtok) * D + head * HD;
+        half_t* oh = (half_t*)g.out_hi + orow;
+        half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
 #pragma unroll
         for (int n = 0; n < ND; ++n)
 #pragma unroll

@@ -75,4 +75,20 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     }
 }
 
+// Element offset of the head slice of operand op (0 = q, 1 = k, 2 = v) of token t of image b:
+//   off = b*sb + t*st + op*sop + head*sh   (branch-free; the four strides are wave-uniform scalars)
+// layout 0: token-major  [B*S][3][H][hd]   (what a plain qkv GEMM writes)
+// layout 1: head-major   [3][B][H][S][hd]  (each (b, head) K / V matrix contiguous: full-line streaming)
+struct QkvStrides { int64_t sb, st, sop, sh; };
+__device__ __forceinline__ QkvStrides qkv_strides(int layout, int S, int B, int H, int HD) {
+    QkvStrides q;
+    const int64_t D = (int64_t)H * HD;
+    if (layout == 0) { q.sb = (int64_t)S * 3 * D; q.st = 3 * D; q.sop = D; q.sh = HD; }
+    else { q.sb = (int64_t)H * S * HD; q.st = HD; q.sop = (int64_t)B * H * S * HD; q.sh = (int64_t)S * HD; }
+    return q;
+}
+__device__ __forceinline__ int64_t qkv_offset(const QkvStrides& q, int b, int t, int op, int head) {
+    return b * q.sb + t * q.st + op * q.sop + head * q.sh;
+}
+
 #define CVLM_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

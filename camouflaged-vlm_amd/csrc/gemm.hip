@@ -325,6 +325,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             } else {
                 off_f = (int64_t)m * g.ldo + n;
                 off_h = (int64_t)m * g.ldoh + n;
+                if (g.hm_S > 0) {                                      // head-major qkv store (4 | hd: never straddles a head)
+                    const int Dh = g.hm_H * g.hm_hd;
+                    const int which = n / Dh, r = n - which * Dh, h = r / g.hm_hd, d = r - h * g.hm_hd;
+                    const int bi = m / g.hm_S, tk = m - bi * g.hm_S;
+                    off_h = ((((int64_t)which * (g.M / g.hm_S) + bi) * g.hm_H + h) * g.hm_S + tk) * g.hm_hd + d;
+                }
             }
             if (g.out_f32) {
                 float* o = g.out_f32 + (int64_t)z * g.stride_o + off_f;
@@ -364,6 +370,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (g.split == 3 && (!g.a_lo || !g.w_lo)) return CVLM_E_BADARG;
     if (!g.out_f32 && !g.out_hi) return CVLM_E_BADARG;
     if (g.ps_c2 > 0 && ((g.ps_c2 & 3) || g.ps_h <= 0 || g.ps_w <= 0)) return CVLM_E_BADARG;
+    if (g.hm_S > 0 && ((g.hm_hd & 3) || g.hm_H <= 0 || (g.M % g.hm_S) || g.N != 3 * g.hm_H * g.hm_hd || !g.out_hi)) return CVLM_E_BADARG;
     GemmParams p;
     p.a = g;
     if (p.a.batch <= 0) p.a.batch = 1;

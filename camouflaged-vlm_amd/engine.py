@@ -217,13 +217,16 @@ class SamEncoder(_Base):
             self.gemm(prm, self.shared, M, residual=x, out_f32=x)
             # :430-446 block
             hip.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, M, D, out_h2=xn)
-            self.gemm(xn, blk["qkv"], M, out_h2=qkv)
+            # qkv is stored head-major [3][B][H][T][hd]: every (image, head) K / V matrix is contiguous, so
+            # the attention kernels stream whole cache lines instead of 160-byte slices of 7.7 KB token rows
+            self.gemm(xn, blk["qkv"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim))
             if blk["window"] > 0:
                 hip.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
-                              pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv)
+                              pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
+                              head_major=True)
             else:
                 hip.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
-                              rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv)
+                              rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
             self.gemm(att, blk["proj"], M, residual=x, out_f32=x)
             hip.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, M, D, out_h2=xn)
             self.gemm(xn, blk["lin1"], M, out_h2=hid, act=ACT_GELU)

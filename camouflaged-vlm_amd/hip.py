@@ -36,6 +36,7 @@ class GemmArgs(C.Structure):
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
         ("alpha", C.c_float), ("act", C.c_int32), ("split", C.c_int32),
         ("ps_h", C.c_int32), ("ps_w", C.c_int32), ("ps_c2", C.c_int32),
+        ("hm_S", C.c_int32), ("hm_H", C.c_int32), ("hm_hd", C.c_int32),
     ]
 
 
@@ -46,7 +47,7 @@ class AttnArgs(C.Structure):
         ("out_hi", C.c_void_p), ("out_lo", C.c_void_p),
         ("B", C.c_int32), ("S", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
         ("mode", C.c_int32), ("grid", C.c_int32), ("window", C.c_int32), ("causal", C.c_int32),
-        ("split_qk", C.c_int32), ("split_pv", C.c_int32), ("scale", C.c_float),
+        ("split_qk", C.c_int32), ("split_pv", C.c_int32), ("scale", C.c_float), ("qkv_layout", C.c_int32),
     ]
 
 
@@ -133,7 +134,8 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          out_f32: Optional[torch.Tensor] = None, ldo: Optional[int] = None, out_h2: Optional[H2] = None,
          ldoh: Optional[int] = None, alpha: float = 1.0, act: int = ACT_NONE, split: int = 3, batch: int = 1,
          stride_a: int = 0, stride_w: int = 0, stride_r: int = 0, stride_o: int = 0, stride_oh: int = 0,
-         pixel_shuffle: Optional[Tuple[int, int, int]] = None) -> None:
+         pixel_shuffle: Optional[Tuple[int, int, int]] = None,
+         head_major: Optional[Tuple[int, int, int]] = None) -> None:
     g = GemmArgs()
     g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
     g.w_hi, g.w_lo, g.ldw, g.stride_w = w.hi.data_ptr(), w.lo.data_ptr(), ldw if ldw is not None else K, stride_w
@@ -147,6 +149,8 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     g.alpha, g.act, g.split = alpha, act, split
     if pixel_shuffle is not None:
         g.ps_h, g.ps_w, g.ps_c2 = pixel_shuffle
+    if head_major is not None:
+        g.hm_S, g.hm_H, g.hm_hd = head_major
     _check(load().cvlm_gemm(C.byref(g), C.c_void_p(_stream())), "cvlm_gemm")
 
 
@@ -199,7 +203,7 @@ def reinterpret_transpose(x: torch.Tensor, B: int, T: int, D: int, out: H2) -> N
 
 def attention(qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, *, mode: int = 0, grid: int = 0, window: int = 0,
               causal: bool = False, pad: Optional[H2] = None, rel_h: Optional[H2] = None, rel_w: Optional[H2] = None,
-              split_qk: int = 3, split_pv: int = 3, scale: Optional[float] = None) -> None:
+              split_qk: int = 3, split_pv: int = 3, scale: Optional[float] = None, head_major: bool = False) -> None:
     a = AttnArgs()
     a.qkv_hi, a.qkv_lo = qkv.hi.data_ptr(), qkv.lo.data_ptr()
     if pad is not None:
@@ -212,6 +216,7 @@ def attention(qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, *, mode: in
     a.mode, a.grid, a.window, a.causal = mode, grid, window, int(causal)
     a.split_qk, a.split_pv = split_qk, split_pv
     a.scale = float(hd) ** -0.5 if scale is None else scale
+    a.qkv_layout = int(head_major)
     _check(load().cvlm_attention(C.byref(a), C.c_void_p(_stream())), "cvlm_attention")
 
 

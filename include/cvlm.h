@@ -54,6 +54,7 @@ typedef struct cvlm_gemm_args {
     int32_t act;
     int32_t split;
     int32_t ps_h, ps_w, ps_c2;
+    int32_t hm_S, hm_H, hm_hd;   /* hm_S > 0: h2 output stored head-major [3][M/hm_S][hm_H][hm_S][hm_hd] (qkv for cvlm_attention layout 1) */
 } cvlm_gemm_args;
 int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
 
@@ -99,7 +100,8 @@ int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, 
  *   image_encoder.py:507-553 (window partition / unpartition incl. zero padding after norm1),
  *   alpha_clip_rw/model.py:223-256 (CLIP ViT-L attention) and nn.MultiheadAttention with the causal
  *   mask (alpha_clip_rw/model.py:388-390, 751-757).
- * qkv: h2 [B*S_img][3*heads*hd] rows = tokens, columns [q | k | v], each heads*hd wide.
+ * qkv: h2 [B*S_img][3*heads*hd] rows = tokens, columns [q | k | v], each heads*hd wide (qkv_layout 0),
+ *      or head-major [3][B][heads][S_img][hd] as written by cvlm_gemm with hm_S > 0 (qkv_layout 1).
  * mode 0: plain (S = tokens per image); mode 1: global with rel-pos on a grid x grid token map;
  * mode 2: windows of `window` x `window` tokens on a grid x grid map, zero padded: pad tokens carry
  *         q = k = v = qkv bias (pad_hi/pad_lo = h2 of the 3*heads*hd bias vector).
@@ -115,6 +117,7 @@ typedef struct cvlm_attn_args {
     int32_t mode, grid, window, causal;
     int32_t split_qk, split_pv;
     float scale;
+    int32_t qkv_layout;          /* 0: token-major [B*S][3][H][hd]; 1: head-major [3][B][H][S][hd] */
 } cvlm_attn_args;
 int cvlm_attention(const cvlm_attn_args* args, void* stream);
 

@@ -94,6 +94,23 @@ def test_gemm_pixel_shuffle(hip):
     assert relerr(out, ref) < 1e-5
 
 
+def to_head_major(qkv, Bn, S, Hh, hd):
+    """[B*S][3][H][hd] -> [3][B][H][S][hd] flattened back to the same (B*S, 3*H*hd) buffer shape."""
+    return qkv.reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).contiguous().reshape(Bn * S, 3 * Hh * hd)
+
+
+def test_gemm_head_major_store(hip):
+    Bn, S, Hh, hd, K = 2, 200, 2, 80, 64
+    M, N = Bn * S, 3 * Hh * hd
+    a, w, bias = rnd(M, K, seed=50), rnd(N, K, seed=51, scale=0.1), rnd(N, seed=52)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    o0, o1 = hip.H2.empty(M, N), hip.H2.empty(M, N)
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o0)
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o1, head_major=(S, Hh, hd))
+    assert torch.equal(o1.t[0].cpu(), to_head_major(o0.t[0].cpu(), Bn, S, Hh, hd))
+    assert torch.equal(o1.t[1].cpu(), to_head_major(o0.t[1].cpu(), Bn, S, Hh, hd))
+
+
 def test_layernorm(hip):
     for M, D, eps in [(37, 1280, 1e-6), (10, 160, 1e-6), (5, 64, 1e-6), (300, 1024, 1e-5)]:
         x, add = rnd(M, D, seed=13) * 3 + 1, rnd(7, D, seed=14)
@@ -144,9 +161,10 @@ def relpos_bias(q, rel_h, rel_w, L):
     return (bh[:, :, :, :, None] + bw[:, :, :, None, :]).reshape(q.shape[0], L * L, L * L)
 
 
+@pytest.mark.parametrize("hm", [False, True])
 @pytest.mark.parametrize("split", [(3, 3), (1, 1)])
 @pytest.mark.parametrize("G", [20, 64])
-def test_attention_global_relpos(hip, G, split):
+def test_attention_global_relpos(hip, G, split, hm):
     Bn, Hh, hd = (2, 2, 80) if G == 20 else (1, 2, 80)
     D, S = Hh * hd, G * G
     qkv = rnd(Bn * S, 3 * D, seed=18)
@@ -154,7 +172,9 @@ def test_attention_global_relpos(hip, G, split):
     Q, RH, RW = dev_h2(hip, qkv), dev_h2(hip, rel_h), dev_h2(hip, rel_w)
     out = hip.H2.empty(Bn * S, D)
     out.t.fill_(float("nan"))
-    hip.attention(Q, out, Bn, S, Hh, hd, mode=1, grid=G, rel_h=RH, rel_w=RW, split_qk=split[0], split_pv=split[1])
+    Qk = hip.H2(torch.stack([to_head_major(Q.t[i], Bn, S, Hh, hd) for i in range(2)])) if hm else Q
+    hip.attention(Qk, out, Bn, S, Hh, hd, mode=1, grid=G, rel_h=RH, rel_w=RW, split_qk=split[0], split_pv=split[1],
+                  head_major=hm)
     x = Q.float().cpu().double().reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).reshape(3, Bn * Hh, S, hd)
     bias = relpos_bias(x[0], RH.float().cpu().double(), RW.float().cpu().double(), G)
     ref = ref_attention(x[0], x[1], x[2], hd ** -0.5, bias=bias)
@@ -162,9 +182,10 @@ def test_attention_global_relpos(hip, G, split):
     assert relerr(out.float(), ref) < (5e-6 if split == (3, 3) else 5e-3)
 
 
+@pytest.mark.parametrize("hm", [False, True])
 @pytest.mark.parametrize("split", [(3, 3), (1, 1)])
 @pytest.mark.parametrize("G", [20, 64])
-def test_attention_window_relpos(hip, G, split):
+def test_attention_window_relpos(hip, G, split, hm):
     ws, Bn, Hh, hd = 14, 2, 2, 80
     D, S = Hh * hd, G * G
     qkv = rnd(Bn * S, 3 * D, seed=21)
@@ -173,8 +194,9 @@ def test_attention_window_relpos(hip, G, split):
     Q, P, RH, RW = dev_h2(hip, qkv), dev_h2(hip, pad), dev_h2(hip, rel_h), dev_h2(hip, rel_w)
     out = hip.H2.empty(Bn * S, D)
     out.t.fill_(float("nan"))
-    hip.attention(Q, out, Bn, S, Hh, hd, mode=2, grid=G, window=ws, pad=P, rel_h=RH, rel_w=RW,
-                  split_qk=split[0], split_pv=split[1])
+    Qk = hip.H2(torch.stack([to_head_major(Q.t[i], Bn, S, Hh, hd) for i in range(2)])) if hm else Q
+    hip.attention(Qk, out, Bn, S, Hh, hd, mode=2, grid=G, window=ws, pad=P, rel_h=RH, rel_w=RW,
+                  split_qk=split[0], split_pv=split[1], head_major=hm)
     # reference: pad the token map with the pad vector (= qkv of a zero token), partition, attend, unpartition
     x = Q.float().cpu().double().reshape(Bn, G, G, 3 * D)
     Gp = -(-G // ws) * ws
