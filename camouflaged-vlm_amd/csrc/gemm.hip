@@ -32,6 +32,8 @@ struct GemmParams {
     cvlm_gemm_args a;
     int nbx, nby;
     int group_m;       // tile rows per L2 super-tile (consecutive ids walk group_m x nbx tiles column-major)
+    int stagger;       // first-round start offset per XCD in units of 64 cycles (0 = off): de-phases the XCDs so
+                       // their epilogue store bursts do not all hit HBM at the same moment
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -59,6 +61,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     // ---- tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
     const int ntiles = p.nbx * p.nby;
     int pid = blockIdx.x;
+    if (p.stagger > 0 && blockIdx.x < 256) {
+        const int xcd = __builtin_amdgcn_readfirstlane(blockIdx.x & 7);
+        for (int i = 0; i < xcd * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = pid & 7, idx = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -255,6 +261,82 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             if (dma) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
+    } else if (NSTAGE == 5) {
+        // Two slots, wave groups staggered by half a K-tile (MT = 8, BK = 32).  Waves 0..3 (group A) and 4..7
+        // (group B) share SIMDs pairwise (wave w and w+4).  Each K-tile has two phases per wave,
+        //   P0: read W + first-half activation fragments, 48 MFMAs, then request the second-half fragments
+        //   P1: 48 MFMAs on the second half
+        // and group B runs one phase behind group A: in every half-tile slot one wave of a SIMD pair is in
+        // its pure-MFMA phase while its partner sits in LDS latency, so the matrix pipe always has work
+        // (microarch guide, "Two waves per SIMD", item 9).  Raw s_barrier at every phase boundary; the group
+        // predicate goes through readfirstlane so the extra barriers are provably wave-uniform.
+        const bool grpB = __builtin_amdgcn_readfirstlane(tid) >= (NWAVE / 2) * 64;
+        const int co = chunk_off(0);
+        half8 wh[4], wl[4], ah[4], al[4];
+        auto mfma_half = [&](int mh, int tn, int sn) {           // 4 m-tiles; optional DMA of tile tn into slot sn
+            const bool dma = tn >= 0 && tn < nk && DBG != 1;
+            const int64_t koff = (int64_t)tn * BK;
+            unsigned char* nxt = smem + sn * STAGE;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (DBG != 2) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        floatx4 c = acc[mh * 4 + mt][nt];
+                        if (SPLIT == 3) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], c, 0, 0, 0);
+                        }
+                        acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
+                    }
+                }
+                if (dma) {
+                    constexpr int PP = PER_WAVE / 4;
+#pragma unroll
+                    for (int j = mt * PP; j < (mt == 3 ? PER_WAVE : (mt + 1) * PP); ++j)
+                        glds16(src[j] + koff, nxt + dst_off[j]);
+                }
+            }
+        };
+        auto read_a = [&](const unsigned char* cur, int mh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *(const half8*)(cur + a_row + (mh * 4 + i) * 16 * ROWB + co);
+                if (SPLIT == 3) al[i] = *(const half8*)(cur + A_PLANE + a_row + (mh * 4 + i) * 16 * ROWB + co);
+            }
+        };
+        auto read_w = [&](const unsigned char* cur) {
+            const unsigned char* pWhi = cur + NPA * A_PLANE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wh[i] = *(const half8*)(pWhi + w_row + i * 16 * ROWB + co);
+                if (SPLIT == 3) wl[i] = *(const half8*)(pWhi + W_PLANE + w_row + i * 16 * ROWB + co);
+            }
+        };
+        // prologue: tile 0 resident for everyone; group B also launches its share of tile 1 (its "P1(-1)")
+        issue(0, 0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (grpB) {
+            if (nk > 1) issue(1, 1);
+            __builtin_amdgcn_s_barrier();                        // B starts one phase late
+        }
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* cur = smem + (t & 1) * STAGE;
+            // ---- P0
+            read_w(cur);
+            read_a(cur, 0);
+            mfma_half(0, grpB ? -1 : t + 1, (t + 1) & 1);        // group A streams tile t+1 under its P0
+            read_a(cur, 1);                                       // second-half fragments: in flight across the barrier
+            if (grpB) wait_vmcnt<0>();                            // B's share of tile t+1 (issued one phase ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every fragment of tile t is in registers
+            __builtin_amdgcn_s_barrier();
+            // ---- P1
+            mfma_half(1, grpB ? t + 2 : -1, t & 1);               // group B streams tile t+2 into the slot it just left
+            if (!grpB) wait_vmcnt<0>();                           // A's share of tile t+1
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!grpB) __builtin_amdgcn_s_barrier();                  // match B's extra leading barrier
     } else {
         // 3-slot ring: tile t computes from slot t%3 while tiles t+1 and t+2 are in flight / landing.
         issue(0, 0);
@@ -378,6 +460,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (group_env < 0) { const char* e = getenv("CVLM_GEMM_GROUP_M"); group_env = e ? atoi(e) : 8; if (group_env < 1) group_env = 1; }
     if (variant_env < 0) { const char* e = getenv("CVLM_GEMM_VARIANT"); variant_env = e ? atoi(e) : 0; }
     p.group_m = group_env;
+    static int stagger_env = -1;
+    if (stagger_env < 0) { const char* e = getenv("CVLM_GEMM_STAGGER"); stagger_env = e ? atoi(e) : 0; }
+    p.stagger = stagger_env;
     hipStream_t s = (hipStream_t)stream;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
     int variant = variant_env;
@@ -407,7 +492,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #define CVLM_LAUNCH_D(SPLIT, WM, WN, NS, BKT, DBG, MT)                                                        \
     do {                                                                                                      \
         constexpr int NPA_ = (SPLIT == 3) ? 2 : 1;                                                            \
-        constexpr int smem_ = (NS == 4 ? 2 : NS) * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
+        constexpr int smem_ = (NS >= 4 ? 2 : NS) * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
         p.nbx = (g.N + WN * 64 - 1) / (WN * 64);                                                              \
         p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                            \
         auto kern_ = gemm_nt_kernel<SPLIT, WM, WN, NS, BKT, DBG, MT>;                                                     \
@@ -419,10 +504,14 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby, p.a.batch), dim3(WM* WN * 64), smem_, s, p);             \
     } while (0)
     if (g.split == 3) {
+        if (variant == 5 && variant_env == 0) variant = 7;      // auto: staggered wave groups (3-5 % over the plain 256^2 loop)
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
         else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
         else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */
         else if (variant == 6) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 0, 8);          /* same tile, mid-tile slot recycling */
+        else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* same tile, wave groups staggered */
+        else if (variant == 17) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 1, 8);
+        else if (variant == 27) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 2, 8);
         else if (variant == 16) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 1, 8);
         else if (variant == 26) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 2, 8);
         else if (variant == 15) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 1, 8);
