@@ -37,7 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "exact"), choices=["exact", "mixed", "fast"])
-    ap.add_argument("--geometry", default="demo", choices=["demo", "tiny"])
+    ap.add_argument("--geometry", default="demo", choices=["demo", "tiny", "hires1536"])
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "encoder"],
+                    help="encoder = SAM ViT-H image encoder only (BASELINE configs[1] / [4] with --geometry hires1536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -62,11 +64,35 @@ def main():
     sys.path.insert(0, cv.DROPIN_DIR)
     from cocotrainers.mapleAlphaCLIP import gather_text_features
 
-    g, c = (spec.DEMO_SAM, spec.DEMO_CLIP) if args.geometry == "demo" else (spec.TINY_SAM, spec.TINY_CLIP)
+    g, c = (spec.DEMO_SAM, spec.DEMO_CLIP) if args.geometry in ("demo", "hires1536") else (spec.TINY_SAM, spec.TINY_CLIP)
+    if args.geometry == "hires1536":
+        import dataclasses
+        g = dataclasses.replace(g, inp_size=1536)            # model *built* at 1536 (pos_embed 96^2, rel_pos 191x80)
+        args.workload = "encoder"
     B = args.batch
     t0 = time.time()
     sd_np = synth.make_full_state_dict(g, c)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    if args.workload == "encoder":
+        from camouflaged_vlm_amd.engine import SamEncoder
+        enc = SamEncoder(sd, g, dev, Precision.named(args.precision))
+        inp = torch.from_numpy(synth.make_inputs(g, c, batch=B, index0=rank * B)[0]).to(dev)
+        for _ in range(args.warmup):
+            enc.forward(inp)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            enc.forward(inp)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        tf_img = {1024: 5.681, 1536: 13.712}.get(g.inp_size)
+        print(json.dumps({"metric": f"images/sec, SAM ViT-H image encoder only at {g.inp_size}x{g.inp_size}",
+                          "value": round(B * args.steps / el, 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                          "config": {"workload": f"SAM ViT-H encoder only, batch {B}, {g.inp_size}^2", "precision": args.precision},
+                          "achieved_tflops_algorithmic": round(B * args.steps / el * tf_img, 1) if tf_img else None}))
+        return
     cas = Cascade(sd, g, c, dev, Precision.named(args.precision))
     eot = host.eot_for_classes(host.ovcamo_constants()["names_test"].tolist())[:c.n_cls_test] \
         if args.geometry == "demo" else spec.default_eot(c, "test")
@@ -124,12 +150,19 @@ def main():
             torch.cuda.synchronize()
         finally:
             hip.gemm = orig
+        traffic = None
+        tfile = os.path.join(REPO, "profiles", "r01_gemm_traffic.json")     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if args.geometry == "demo" and args.precision == "exact" and B == 8 and os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = round(json.load(f)["traffic_bytes_per_launch"])
         flops = sum(r[0] for r in records)
         ms = sum(r[1].elapsed_time(r[2]) for r in records)
         achieved = flops / (ms * 1e-3) / 1e12
         roofline = {"kernel": "gemm_nt_kernel<split=%d>" % cas.prec.gemm, "bound": "mfma",
                     "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) and "
+                                    "WRITE_SIZE passes of this command (profiles/r01_gemm_traffic.json)" if traffic else None,
                     "launches": len(records), "avg_launch_us": round(1e3 * ms / len(records), 2),
                     "algorithmic_gflop_per_launch": round(flops / len(records) / 1e9, 3),
                     "gemm_share_of_step": round(ms * 1e-3 / (max(1, min(args.steps, 2))) / (elapsed / args.steps), 3)}
