@@ -571,6 +571,9 @@ class Cascade(_Base):
                       self.dev(sd["sam_visual_proj.2.weight"]), self.dev(sd["sam_visual_proj.2.bias"]))
         self.tproj = (self.dev(sd["sam_text_proj.0.weight"]), self.dev(sd["sam_text_proj.0.bias"]),
                       Linear(sd["sam_text_proj.1.weight"], sd["sam_text_proj.1.bias"], device))
+        import os
+        self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "0") == "1"      # +0.5 % only: off by default
+        self._side = None
 
     def sparse_prompts(self, img_f: torch.Tensor, txt_f: torch.Tensor, B: int) -> torch.Tensor:
         """models/sam_maskdecoder_edge.py:342-344."""
@@ -590,8 +593,20 @@ class Cascade(_Base):
     def infer_test(self, inp, clip_image, clip_mask, taps: Optional[dict] = None) -> torch.Tensor:
         g = self.g
         B = inp.shape[0]
-        feats = self.encoder.forward(inp, taps)
-        img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
+        # CLIP pass 1 only needs (clip_image, clip_mask): it runs on a side stream underneath the SAM encoder so
+        # its small grids (228..1184 workgroups) fill CUs the big encoder GEMMs leave idle at tile boundaries
+        if self.overlap_clip:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
+            feats = self.encoder.forward(inp, taps)
+            main.wait_stream(self._side)
+        else:
+            feats = self.encoder.forward(inp, taps)
+            img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
         sparse = self.sparse_prompts(img_f, txt_f, B)
         low = self.decoder.forward(feats, sparse, self.no_mask, self.gauss, B, taps)
         masks = torch.empty(B, 1, g.inp_size, g.inp_size, device=self.device)
