@@ -21,7 +21,7 @@ EXPORTS = [
     "cvlm_abi_version", "cvlm_target_arch", "cvlm_gemm", "cvlm_layernorm", "cvlm_add_rows", "cvlm_split_f32",
     "cvlm_patchify", "cvlm_im2col3x3", "cvlm_reinterpret_transpose", "cvlm_attention", "cvlm_small_attention",
     "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
-    "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add",
+    "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
 ]
 
 
@@ -274,3 +274,21 @@ def clip_head(img, txt, logit_scale_exp: float, B: int, Cc: int, D: int, img_n, 
 def normalize_add(x, add, R: int, D: int, out) -> None:
     _check(load().cvlm_normalize_add(C.c_void_p(x.data_ptr()), C.c_void_p(_p(add)), C.c_int32(R), C.c_int32(D),
                                      C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), "cvlm_normalize_add")
+
+
+def resample_u8(src: torch.Tensor, bounds: torch.Tensor, kk: torch.Tensor, n_out: int, axis: int, dst: torch.Tensor) -> None:
+    """src/dst uint8 [N][H][W][C]; bounds int32 [n_out][2]; kk int32 [n_out][ksize] (device tensors)."""
+    N, H, W, Cc = src.shape
+    _check(load().cvlm_resample_u8(C.c_void_p(src.data_ptr()), C.c_int32(N), C.c_int32(H), C.c_int32(W), C.c_int32(Cc),
+                                   C.c_void_p(bounds.data_ptr()), C.c_void_p(kk.data_ptr()), C.c_int32(kk.shape[1]),
+                                   C.c_int32(n_out), C.c_int32(axis), C.c_void_p(dst.data_ptr()), C.c_void_p(_stream())),
+           "cvlm_resample_u8")
+
+
+def u8_to_tensor(src: torch.Tensor, top: int, left: int, ch: int, cw: int, mean: torch.Tensor, std: torch.Tensor,
+                 dst: torch.Tensor) -> None:
+    N, H, W, Cc = src.shape
+    _check(load().cvlm_u8_to_tensor(C.c_void_p(src.data_ptr()), C.c_int32(N), C.c_int32(H), C.c_int32(W), C.c_int32(Cc),
+                                    C.c_int32(top), C.c_int32(left), C.c_int32(ch), C.c_int32(cw),
+                                    C.c_void_p(mean.data_ptr()), C.c_void_p(std.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                    C.c_void_p(_stream())), "cvlm_u8_to_tensor")

@@ -1,0 +1,110 @@
+"""GPU preprocessing in front of the hot path: uint8 HWC image on the device ->
+``inp`` (1,3,S,S), ``clip_image`` (1,3,R,R), ``clip_mask`` (1,1,R,R) exactly as demo.py:93-107 /
+datasets/wrappers.py:22-62 build them with torchvision + Pillow on the CPU.  The coefficient tables of
+Pillow's resample are computed on the host once per (in, out, filter) and cached; all per-pixel work is in
+camouflaged-vlm_amd/csrc/preprocess.hip."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+OPENAI_MEAN, OPENAI_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+_PRECISION_BITS = 32 - 8 - 2
+
+
+def _coeffs(in_size: int, out_size: int, filt: str) -> Tuple[np.ndarray, np.ndarray]:
+    """Pillow precompute_coeffs + normalize_coeffs_8bpc (libImaging/Resample.c), vectorised per output index."""
+    support0 = 1.0 if filt == "bilinear" else 2.0
+    scale = filterscale = float(in_size) / out_size
+    filterscale = max(filterscale, 1.0)
+    support = support0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        x = np.abs((np.arange(xmax) + xmin - center + 0.5) * ss)
+        if filt == "bilinear":
+            w = np.where(x < 1.0, 1.0 - x, 0.0)
+        else:
+            a = -0.5
+            w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1,
+                         np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+        ww = 0.0
+        for v in w:                      # same left-to-right double accumulation as the C loop
+            ww += float(v)
+        if ww != 0.0:
+            w = w / ww
+        kk[xx, :xmax] = [int(-0.5 + v * (1 << _PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PRECISION_BITS))
+                         for v in w.tolist()]
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+class GpuPreprocess:
+    def __init__(self, inp_size: int = 1024, clip_size: int = 336, device="cuda"):
+        self.S, self.R, self.device = inp_size, clip_size, torch.device(device)
+        self._tables: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        f = lambda v: torch.tensor(v, dtype=torch.float32, device=self.device)
+        self.im_mean, self.im_std, self.cl_mean, self.cl_std = f(IMAGENET_MEAN), f(IMAGENET_STD), f(OPENAI_MEAN), f(OPENAI_STD)
+
+    def _table(self, n_in: int, n_out: int, filt: str):
+        key = (n_in, n_out, filt)
+        if key not in self._tables:
+            b, k = _coeffs(n_in, n_out, filt)
+            self._tables[key] = (torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device))
+        return self._tables[key]
+
+    def resize(self, img: torch.Tensor, out_h: int, out_w: int, filt: str) -> torch.Tensor:
+        """uint8 [N][H][W][C] on the device -> uint8 [N][out_h][out_w][C] (== PIL.Image.resize)."""
+        N, H, W, C = img.shape
+        x = img.contiguous()
+        if out_w != W:
+            b, k = self._table(W, out_w, filt)
+            y = torch.empty(N, H, out_w, C, dtype=torch.uint8, device=self.device)
+            hip.resample_u8(x, b, k, out_w, 1, y)
+            x = y
+        if out_h != H:
+            b, k = self._table(H, out_h, filt)
+            y = torch.empty(N, out_h, x.shape[2], C, dtype=torch.uint8, device=self.device)
+            hip.resample_u8(x, b, k, out_h, 0, y)
+            x = y
+        return x
+
+    def sam_input(self, img: torch.Tensor) -> torch.Tensor:
+        """transforms.Resize((S,S)) -> ToTensor -> Normalize(ImageNet): uint8 [N][H][W][3] -> f32 (N,3,S,S)."""
+        img = img.unsqueeze(0) if img.dim() == 3 else img
+        r = self.resize(img, self.S, self.S, "bilinear")
+        out = torch.empty(r.shape[0], 3, self.S, self.S, device=self.device)
+        hip.u8_to_tensor(r, 0, 0, self.S, self.S, self.im_mean, self.im_std, out)
+        return out
+
+    def clip_input(self, img: torch.Tensor) -> torch.Tensor:
+        """Resize(R, BICUBIC) -> CenterCrop(R) -> ToTensor -> Normalize(OpenAI) -> f32 (N,3,R,R)."""
+        img = img.unsqueeze(0) if img.dim() == 3 else img
+        N, H, W, _ = img.shape
+        R = self.R
+        rh, rw = (int(R * H / W), R) if W <= H else (R, int(R * W / H))
+        r = self.resize(img, rh, rw, "bicubic")
+        top, left = int(round((rh - R) / 2.0)), int(round((rw - R) / 2.0))
+        out = torch.empty(N, 3, R, R, device=self.device)
+        hip.u8_to_tensor(r, top, left, R, R, self.cl_mean, self.cl_std, out)
+        return out
+
+    def clip_mask(self, n: int) -> torch.Tensor:
+        """mask_transform on an all-255 mask (wrappers.py:62): the constant (1 - 0.5) / 0.26."""
+        return torch.full((n, 1, self.R, self.R), (1.0 - 0.5) / 0.26, dtype=torch.float32, device=self.device)
+
+    def __call__(self, img: torch.Tensor):
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        return self.sam_input(img), self.clip_input(img), self.clip_mask(img.shape[0])

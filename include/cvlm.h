@@ -166,6 +166,18 @@ int cvlm_clip_head(const float* img, const float* txt, float logit_scale_exp, in
 /* Row L2 normalise + add: out[r] = x[r]/||x[r]|| + add[r] (text bank, mapleAlphaCLIP.py:290-291). */
 int cvlm_normalize_add(const float* x, const float* add, int32_t R, int32_t D, float* out, void* stream);
 
+/* ---- N1: preprocessing before the path (demo.py:93-107, datasets/wrappers.py:22-27,
+ * alpha_clip_rw/alpha_clip.py:79-94).  torchvision Resize on a PIL image == PIL.Image.resize (Pillow
+ * libImaging/Resample.c, 8-bit path).  One separable pass of that resample on uint8 NHWC images:
+ * output index o along `axis` (0 = rows, 1 = columns) = clamp8((2^21 + sum_t src[lo_o + t] * kk[o][t]) >> 22),
+ * (lo_o, count_o) = bounds[o]; bounds/kk are the host-side Pillow coefficient tables (int32, device memory). */
+int cvlm_resample_u8(const uint8_t* src, int32_t N, int32_t H, int32_t W, int32_t C, const int32_t* bounds,
+                     const int32_t* kk, int32_t ksize, int32_t n_out, int32_t axis, uint8_t* dst, void* stream);
+
+/* ToTensor + Normalize (+ CenterCrop window): uint8 [N][H][W][C] -> f32 [N][C][ch][cw] = (x/255 - mean[c]) / std[c]. */
+int cvlm_u8_to_tensor(const uint8_t* src, int32_t N, int32_t H, int32_t W, int32_t C, int32_t top, int32_t left,
+                      int32_t ch, int32_t cw, const float* mean, const float* stdv, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

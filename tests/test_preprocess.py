@@ -1,0 +1,85 @@
+"""N1: preprocessing before the path.  CPU: the numpy restatement of Pillow's resample is pinned
+bit-for-bit to golden vectors produced by Pillow (tools/make_preprocess_golden.py) and, when Pillow is importable, to
+Pillow directly.  GPU: the HIP kernels must equal the oracle bit-for-bit (uint8) / exactly (fp32 normalise)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import preprocess_oracle as P
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    with np.load(os.path.join(golden_dir, "preprocess.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _big(gold):
+    rng = np.random.default_rng(int(gold["big_seed"][0]))
+    for _, h, w, _, _, _ in [("a", 97, 131, 0, 0, 0), ("b", 60, 45, 0, 0, 0), ("c", 300, 200, 0, 0, 0),
+                             ("d", 50, 70, 0, 0, 0), ("e", 90, 160, 0, 0, 0)]:
+        rng.integers(0, 256, (h, w, 3), dtype=np.uint8)           # replay the generator's stream
+    return rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+
+
+def test_oracle_resample_matches_pillow_golden(gold):
+    for name in "abcde":
+        h, w, oh, ow, f = gold[f"meta_{name}"].tolist()
+        got = P.resize_u8(gold[f"in_{name}"], oh, ow, "bicubic" if f else "bilinear")
+        assert np.array_equal(got, gold[f"out_{name}"]), name
+
+
+def test_oracle_full_size_checksums(gold):
+    big = _big(gold)
+    assert zlib.crc32(big.tobytes()) == int(gold["big_crc"][0])
+    assert zlib.crc32(P.resize_u8(big, 1024, 1024, "bilinear").tobytes()) == int(gold["big_crc"][1])
+    assert zlib.crc32(P.resize_u8(big, 336, 448, "bicubic").tobytes()) == int(gold["big_crc"][2])
+
+
+def test_oracle_against_live_pillow_if_present():
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, (123, 77, 3), dtype=np.uint8)
+    for (oh, ow, f, pf) in [(64, 200, "bilinear", Image.BILINEAR), (336, 210, "bicubic", Image.BICUBIC)]:
+        assert np.array_equal(P.resize_u8(a, oh, ow, f), np.asarray(Image.fromarray(a).resize((ow, oh), pf)))
+
+
+def test_host_coefficient_tables_equal_oracle():
+    from camouflaged_vlm_amd.preprocess import _coeffs
+    for n_in, n_out, f in [(640, 1024, "bilinear"), (480, 336, "bicubic"), (97, 64, "bilinear"), (50, 120, "bicubic")]:
+        b, k = _coeffs(n_in, n_out, f)
+        b2, k2, _ = P.precompute_coeffs(n_in, n_out, f)
+        assert np.array_equal(b, b2) and np.array_equal(k, k2)
+
+
+def test_clip_geometry_helpers():
+    assert P.clip_resize_shape(480, 640, 336) == (336, 448) and P.clip_resize_shape(640, 480, 336) == (448, 336)
+    assert P.center_crop_box(336, 448, 336) == (0, 56)
+    x = P.clip_input(np.full((50, 70, 3), 255, np.uint8), 32)
+    assert x.shape == (3, 32, 32) and abs(float(x[0, 0, 0]) - (1 - 0.48145466) / 0.26862954) < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_bit_exact(gold):
+    from camouflaged_vlm_amd.preprocess import GpuPreprocess
+    pp = GpuPreprocess(inp_size=1024, clip_size=336)
+    for name in "abcde":
+        h, w, oh, ow, f = gold[f"meta_{name}"].tolist()
+        img = torch.from_numpy(gold[f"in_{name}"]).cuda().unsqueeze(0)
+        got = pp.resize(img, oh, ow, "bicubic" if f else "bilinear")[0].cpu().numpy()
+        assert np.array_equal(got, gold[f"out_{name}"]), name
+    big = _big(gold)
+    dev = torch.from_numpy(big).cuda()
+    inp, clip_image, clip_mask = pp(dev)
+    torch.cuda.synchronize()
+    assert inp.shape == (1, 3, 1024, 1024) and clip_image.shape == (1, 3, 336, 336) and clip_mask.shape == (1, 1, 336, 336)
+    assert np.array_equal(inp[0].cpu().numpy(), P.sam_input(big, 1024))           # fp32: exact
+    assert np.array_equal(clip_image[0].cpu().numpy(), P.clip_input(big, 336))
+    assert abs(float(clip_mask[0, 0, 0, 0]) - 1.9230769) < 1e-6
+    # batch of two equal-size images == two single calls
+    two = torch.stack([dev, torch.flip(dev, dims=(1,))])
+    b2 = pp.sam_input(two)
+    assert torch.equal(b2[0], inp[0]) and torch.equal(b2[1], pp.sam_input(torch.flip(dev, dims=(1,)).contiguous())[0])
