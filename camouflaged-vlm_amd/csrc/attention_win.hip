@@ -65,11 +65,16 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     const int SI = g.grid * g.grid;
     const QkvStrides QS = qkv_strides(g.qkv_layout, SI, g.B, g.heads, HD);
 
-    // ---- constant one-hot block of K_aug
-    for (int i = tid; i < 224 * 32; i += NT) {
-        const int slot = i >> 5, c = i & 31;
-        const int kh = slot / L, kw = slot - kh * L;
-        OH[slot * OP + c] = (half_t)((slot < S_SEQ && (c == kh || c == 14 + kw)) ? 1.0f : 0.0f);
+    // ---- constant one-hot block of K_aug: one slot row per thread (224 rows, four 16-byte stores each)
+    if (tid < 224) {
+        const int kh = tid / L, kw = tid - kh * L;
+        half_t row[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) row[c] = (half_t)((tid < S_SEQ && (c == kh || c == 14 + kw)) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8)
+            *(half8*)(OH + tid * OP + 8 * c8) = half8{row[8 * c8], row[8 * c8 + 1], row[8 * c8 + 2], row[8 * c8 + 3],
+                                                      row[8 * c8 + 4], row[8 * c8 + 5], row[8 * c8 + 6], row[8 * c8 + 7]};
     }
 
     // ---- queries

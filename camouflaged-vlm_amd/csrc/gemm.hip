@@ -261,6 +261,59 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             if (dma) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
+    } else if (NSTAGE == 6) {
+        // ONE slot, recycled mid-tile (MT = 8, BK = 32): 48 KB of LDS for a 256 x 128 tile with 4 waves, so TWO
+        // workgroups share a CU -- one workgroup's LDS latency, barriers and, above all, its store-bound epilogue
+        // (25 % of a K = 1280 GEMM) run underneath the other's MFMAs.
+        issue(0, 0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        const int co = chunk_off(0);
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* pAhi = smem;
+            const unsigned char* pAlo = smem + A_PLANE;
+            const unsigned char* pWhi = smem + NPA * A_PLANE;
+            const unsigned char* pWlo = pWhi + W_PLANE;
+            half8 wh[4], wl[4], ah[MT], al[MT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                wh[i] = *(const half8*)(pWhi + w_row + i * 16 * ROWB + co);
+                if (SPLIT == 3) wl[i] = *(const half8*)(pWlo + w_row + i * 16 * ROWB + co);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = *(const half8*)(pAhi + a_row + i * 16 * ROWB + co);
+                if (SPLIT == 3) al[i] = *(const half8*)(pAlo + a_row + i * 16 * ROWB + co);
+            }
+            const bool dma = (t + 1 < nk) && DBG != 1;
+            const int64_t koff = (int64_t)(t + 1) * BK;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (DBG != 2) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        floatx4 c = acc[mt][nt];
+                        if (SPLIT == 3) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], c, 0, 0, 0);
+                        }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
+                    }
+                }
+                if (mt == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tile t is in registers everywhere ...
+                    __builtin_amdgcn_s_barrier();                        // ... so the slot may be overwritten
+                }
+                if (dma && mt >= 1 && mt <= 4) {
+                    constexpr int PP = (PER_WAVE + 3) / 4;
+#pragma unroll
+                    for (int j = (mt - 1) * PP; j < (mt * PP < PER_WAVE ? mt * PP : PER_WAVE); ++j)
+                        glds16(src[j] + koff, smem + dst_off[j]);
+                }
+            }
+            wait_vmcnt<0>();                                             // tile t+1 landed (this wave's share)
+            __builtin_amdgcn_s_barrier();
+        }
     } else if (NSTAGE == 5) {
         // Two slots, wave groups staggered by half a K-tile (MT = 8, BK = 32).  Waves 0..3 (group A) and 4..7
         // (group B) share SIMDs pairwise (wave w and w+4).  Each K-tile has two phases per wave,
@@ -570,7 +623,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             variant = (c5 <= c2 && c5 <= c1) ? 5 : (c2 <= c1 ? 2 : 1);
         } else {
             // mid-size grids: 256x128 pays off on the long-M SAM shapes, 128^2 on the short CLIP ones
-            const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / (g.M >= 16384 ? 1.08 : 0.97);
+            const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / (g.M >= 16384 ? 1.08 : 1.05);
             variant = (c2 < c1) ? 2 : 1;
         }
     }
@@ -578,7 +631,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #define CVLM_LAUNCH_D(SPLIT, WM, WN, NS, BKT, DBG, MT)                                                        \
     do {                                                                                                      \
         constexpr int NPA_ = (SPLIT == 3) ? 2 : 1;                                                            \
-        constexpr int smem_ = (NS >= 4 ? 2 : NS) * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
+        constexpr int smem_ = (NS == 6 ? 1 : (NS >= 4 ? 2 : NS)) * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
         p.nbx = (g.N + WN * 64 - 1) / (WN * 64);                                                              \
         p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                            \
         auto kern_ = gemm_nt_kernel<SPLIT, WM, WN, NS, BKT, DBG, MT>;                                                     \
@@ -596,6 +649,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */
         else if (variant == 6) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 0, 8);          /* same tile, mid-tile slot recycling */
         else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* same tile, wave groups staggered */
+        else if (variant == 8) CVLM_LAUNCH_D(3, 2, 2, 6, 32, 0, 8);          /* 256x128, 4 waves, one recycled slot, 2 WG/CU */
+        else if (variant == 18) CVLM_LAUNCH_D(3, 2, 2, 6, 32, 1, 8);
+        else if (variant == 28) CVLM_LAUNCH_D(3, 2, 2, 6, 32, 2, 8);
         else if (variant == 17) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 1, 8);
         else if (variant == 27) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 2, 8);
         else if (variant == 37) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 3, 8);        /* probe: no epilogue stores */
