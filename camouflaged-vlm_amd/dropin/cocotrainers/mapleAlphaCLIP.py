@@ -94,8 +94,10 @@ class CustomCLIP(nn.Module):
                 nk = k
             else:
                 continue
-            if nk in own and tuple(own[nk].shape) == tuple(v.shape):
-                own[nk].data.copy_(v.detach().float())
+            if nk not in own:
+                continue
+            if tuple(own[nk].shape) == tuple(v.shape) or (own[nk].numel() == 1 and v.numel() == 1):
+                own[nk].data.copy_(v.detach().float().reshape(own[nk].shape))
 
     def load_text_features(self, train_text_features, test_text_features):
         self.train_text_features = train_text_features

@@ -171,3 +171,55 @@ def test_text_bank_sharding_over_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_openai_clip_key_mapping():
+    """N3 (shape-level): OpenAI CLIP state_dict keys map onto the drop-in's keys as alpha_clip_rw/model.py:864-881 does
+    (visual.* -> image_encoder.* with in_proj_weight -> in_proj.weight; text transformer under text_encoder.*)."""
+    if cv.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, cv.DROPIN_DIR)
+    from cocotrainers.mapleAlphaCLIP import CustomCLIP
+    c = spec.TINY_CLIP
+    W, T = c.vision_width, c.text_width
+    fake = {
+        "visual.conv1.weight": torch.full((W, 3, 14, 14), 0.5),
+        "visual.class_embedding": torch.full((W,), 0.25),
+        "visual.transformer.resblocks.0.attn.in_proj_weight": torch.full((3 * W, W), 0.125),
+        "visual.transformer.resblocks.0.attn.in_proj_bias": torch.full((3 * W,), -1.0),
+        "visual.proj": torch.full((W, c.embed_dim), 2.0),
+        "transformer.resblocks.1.attn.in_proj_weight": torch.full((3 * T, T), 3.0),
+        "transformer.resblocks.1.mlp.c_fc.bias": torch.full((4 * T,), 4.0),
+        "positional_embedding": torch.full((c.context_length, T), 5.0),
+        "text_projection": torch.full((T, c.embed_dim), 6.0),
+        "ln_final.weight": torch.full((T,), 7.0),
+        "logit_scale": torch.tensor(4.6052),
+        "token_embedding.weight": torch.zeros(10, T),                 # not part of the drop-in's state_dict
+        "visual.positional_embedding": torch.zeros(3, W),             # wrong shape: must be ignored, not crash
+    }
+    m = CustomCLIP(geometry=c, clip_model=fake)
+    sd = m.state_dict()
+    assert float(sd["image_encoder.conv1.weight"].mean()) == 0.5
+    assert float(sd["image_encoder.transformer.resblocks.0.attn.in_proj.weight"].mean()) == 0.125
+    assert float(sd["image_encoder.transformer.resblocks.0.attn.in_proj.bias"].mean()) == -1.0
+    assert float(sd["image_encoder.proj"].mean()) == 2.0
+    assert float(sd["text_encoder.transformer.resblocks.1.attn.in_proj_weight"].mean()) == 3.0
+    assert float(sd["text_encoder.transformer.resblocks.1.mlp.c_fc.bias"].mean()) == 4.0
+    assert float(sd["text_encoder.positional_embedding"].mean()) == 5.0
+    assert float(sd["text_encoder.text_projection"].mean()) == 6.0 and float(sd["text_encoder.ln_final.weight"].mean()) == 7.0
+    assert abs(float(sd["logit_scale"]) - 4.6052) < 1e-6
+    assert float(sd["image_encoder.conv1_alpha.weight"].abs().max()) > 0      # untouched synthetic init
+
+
+def test_partial_checkpoint_loads_non_strict():
+    """SAM base checkpoints are loaded with strict=False in the reference (train_...py:296-299)."""
+    if cv.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, cv.DROPIN_DIR)
+    import models
+    g = spec.TINY_SAM
+    enc = dict(patch_size=16, embed_dim=g.embed_dim, depth=g.depth, num_heads=g.num_heads, mlp_ratio=4, out_chans=256,
+               qkv_bias=True, use_rel_pos=True, window_size=14, global_attn_indexes=[1, 3], prompt_embed_dim=256)
+    m = models.make({"name": "sam_maskdecoder_edge", "args": {"inp_size": 320, "loss": "iou", "encoder_mode": enc}})
+    part = {"image_encoder.patch_embed.proj.bias": torch.full((g.embed_dim,), 9.0), "unknown.key": torch.zeros(1)}
+    res = m.load_state_dict(part, strict=False)
+    assert "unknown.key" in res.unexpected_keys and len(res.missing_keys) > 100
+    assert float(m.state_dict()["image_encoder.patch_embed.proj.bias"].mean()) == 9.0
