@@ -1,0 +1,290 @@
+"""Evaluation tail on the device: what the reference does with `infer_test`'s output.
+
+The reference pulls every 1024x1024 float mask to the host, resizes it with cv2 and walks it several times in
+numpy (test_ovcos_maskdecoder_edge.py:116-136, recorder/ovcos_metricer.py).  Every metric it then computes except the
+weighted F-measure only depends on the uint8 mask through counts: per S-measure quadrant, per ground-truth class, per
+level.  `mask_counts` produces exactly those counters on the GPU (`csrc/evaltail.hip`); the functions below turn the
+8 KB of counters per image into MAE, adaptive / changeable F, E and IoU measures and the S-measure in float64.
+
+There is no CPU path: `mask_counts` and `DeviceClassification` raise if the HIP library is missing.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hip
+
+_EPS = np.spacing(1)
+CURVE_METRICS = ("fm", "em", "iou")
+SUPPORTED = ("sm", "mae", "fm", "em", "iou")
+
+
+# ---- device side -----------------------------------------------------------------------------------------------------
+def mask_to_u8(logits: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """logits (N,1,Hs,Ws) or (N,Hs,Ws) f32 on the GPU -> uint8 (N,h,w): sigmoid, bilinear resize, *255, truncate."""
+    if logits.dim() == 4:
+        logits = logits[:, 0]
+    logits = logits.float().contiguous()
+    out = torch.empty((logits.shape[0], h, w), dtype=torch.uint8, device=logits.device)
+    hip.mask_to_u8(logits, h, w, out)
+    return out
+
+
+def mask_counts(pre: torch.Tensor, gt: torch.Tensor):
+    """pre / gt uint8 (N,h,w) on the GPU -> (stats int64 (N,3), hist int32 (N,4,2,256)) device tensors."""
+    n = pre.shape[0]
+    stats = torch.empty((n, 3), dtype=torch.int64, device=pre.device)
+    hist = torch.empty((n, 4, 2, 256), dtype=torch.int32, device=pre.device)
+    hip.mask_joint_hist(pre.contiguous(), gt.contiguous(), stats, hist)
+    return stats, hist
+
+
+# ---- counters -> metrics (host, float64, 2048 numbers per image) ------------------------------------------------------
+def _levels(total: np.ndarray) -> np.ndarray:
+    """`prepare_data` of pysodmetrics 1.4.2 per level: v / 255, min-max normalised over the levels present."""
+    p = np.arange(256, dtype=np.float64) / 255
+    present = np.nonzero(total.sum(axis=0))[0]
+    lo, hi = p[present[0]], p[present[-1]]
+    return (p - lo) / (hi - lo) if hi != lo else p
+
+
+def _cumulative(norm: np.ndarray, total: np.ndarray):
+    q = (norm * 255).astype(np.uint8).astype(np.int64)           # `(pred * 255).astype(np.uint8)` per level
+    present = total.sum(axis=0) > 0
+    fg = np.bincount(q[present], weights=total[1][present], minlength=256).astype(np.int64)
+    bg = np.bincount(q[present], weights=total[0][present], minlength=256).astype(np.int64)
+    return np.cumsum(fg[::-1]), np.cumsum(bg[::-1])
+
+
+def _em(fg_fg, fg_bg, gt_fg, size):
+    pred_fg = fg_fg + fg_bg
+    pred_bg = size - pred_fg
+    if gt_fg == 0:
+        s = pred_bg
+    elif gt_fg == size:
+        s = pred_fg
+    else:
+        bg_fg = gt_fg - fg_fg
+        bg_bg = pred_bg - bg_fg
+        mp, mg = pred_fg / size, gt_fg / size
+        combos = ((1 - mp, 1 - mg), (1 - mp, 0 - mg), (0 - mp, 1 - mg), (0 - mp, 0 - mg))
+        s = 0
+        for part, (dp, dg) in zip((fg_fg, fg_bg, bg_fg, bg_bg), combos):
+            s = s + ((2 * (dp * dg) / (dp ** 2 + dg ** 2 + _EPS)) + 1) ** 2 / 4 * part
+    return s / (size - 1 + _EPS)
+
+
+def _moments(cnt: np.ndarray, val: np.ndarray):
+    """count-weighted (n, mean, sum of squared deviations) of `val`."""
+    n = cnt.sum()
+    with np.errstate(all="ignore"):
+        mean = (cnt * val).sum() / n
+        ssd = (cnt * (val - mean) ** 2).sum()
+    return n, mean, ssd
+
+
+def _ssim(cnt: np.ndarray, norm: np.ndarray):
+    """S-measure region term on one quadrant; cnt (2,256)."""
+    with np.errstate(all="ignore"):
+        n, x, sxx = _moments(cnt.sum(axis=0), norm)
+        y = cnt[1].sum() / n
+        sx = sxx / (n - 1)
+        sy = (cnt[1].sum() * (1 - y) ** 2 + cnt[0].sum() * y ** 2) / (n - 1)
+        sxy = ((cnt[1] * (norm - x)).sum() * (1 - y) + (cnt[0] * (norm - x)).sum() * (0 - y)) / (n - 1)
+        alpha = 4 * x * y * sxy
+        beta = (x ** 2 + y ** 2) * (sx + sy)
+        if alpha != 0:
+            return alpha / (beta + _EPS)
+        return 1 if beta == 0 else 0
+
+
+def _sm(hist: np.ndarray, norm: np.ndarray, stats: np.ndarray, h: int, w: int, alpha: float = 0.5) -> float:
+    total = hist.sum(axis=0)
+    size = h * w
+    n1 = int(total[1].sum())
+    mean_all = float((total.sum(axis=0) * norm).sum() / size)
+    if n1 == 0:
+        return 1 - mean_all
+    if n1 == size:
+        return mean_all
+    u = n1 / size
+    with np.errstate(all="ignore"):
+        def s_object(cnt, val):
+            n, x, ssd = _moments(cnt, val)
+            sigma = np.sqrt(ssd / (n - 1))
+            return 2 * x / (x ** 2 + 1 + sigma + _EPS)
+        obj = u * s_object(total[1], norm) + (1 - u) * s_object(total[0], 1 - norm)
+        cnt, sx, sy = (int(v) for v in stats)
+        cx, cy = int(np.round(sx / cnt)) + 1, int(np.round(sy / cnt)) + 1
+        w1, w2, w3 = cx * cy / size, cy * (w - cx) / size, (h - cy) * cx / size
+        w4 = 1 - w1 - w2 - w3
+        reg = sum(wk * _ssim(hist[k], norm) for k, wk in enumerate((w1, w2, w3, w4)))
+        return max(0, alpha * obj + (1 - alpha) * reg)
+
+
+def metrics_from_counts(stats: np.ndarray, hist: np.ndarray, h: int, w: int, same_class: bool = True,
+                        metric_names: Sequence[str] = SUPPORTED) -> Dict[str, object]:
+    """One image: stats (3,), hist (4,2,256) -> the per-image values OVCOSMetricer.step records
+    (recorder/ovcos_metricer.py:13-141), zeroed (MAE: 1) when the predicted class is wrong."""
+    hist = np.asarray(hist).astype(np.int64).reshape(4, 2, 256)
+    total = hist.sum(axis=0)
+    size = h * w
+    assert int(total.sum()) == size, (int(total.sum()), size)
+    norm = _levels(total)
+    both = total.sum(axis=0)
+    n1 = int(total[1].sum())
+    thr = min(2 * float((both * norm).sum() / size), 1)
+    binary = norm >= thr
+    out: Dict[str, object] = {}
+    if "sm" in metric_names:
+        out["sm"] = float(_sm(hist, norm, np.asarray(stats), h, w))
+    if "mae" in metric_names:
+        out["mae"] = float(((total[1] * np.abs(norm - 1)).sum() + (total[0] * np.abs(norm)).sum()) / size)
+    tp_a, fp_a = int(total[1][binary].sum()), int(total[0][binary].sum())
+    tp, fp = _cumulative(norm, total)
+    if "fm" in metric_names:
+        beta = 0.3
+        if tp_a == 0:
+            out["fm_adp"] = 0.0
+        else:
+            pre, rec = tp_a / (tp_a + fp_a), tp_a / n1
+            out["fm_adp"] = float((1 + beta) * pre * rec / (beta * pre + rec))
+        ps = tp + fp
+        ps[ps == 0] = 1
+        precisions, recalls = tp / ps, tp / max(n1, 1)
+        num = (1 + beta) * precisions * recalls
+        out["fm_curve"] = num / np.where(num == 0, 1, beta * precisions + recalls)
+    if "em" in metric_names:
+        out["em_adp"] = float(_em(tp_a, fp_a, n1, size))
+        out["em_curve"] = np.asarray(_em(tp, fp, n1, size), dtype=np.float64)
+    if "iou" in metric_names:
+        union = tp_a + fp_a + (n1 - tp_a)
+        out["iou_adp"] = 0.0 if union == 0 else float(tp_a / union)
+        den = np.array(tp + (n1 - tp) + fp, dtype=np.float64)
+        np.divide(tp, den, out=den, where=den != 0)
+        out["iou_curve"] = den
+    if not same_class:
+        out = {k: (np.ones_like(v) if k == "mae" else np.zeros_like(v)) * 1.0 for k, v in out.items()}
+    return out
+
+
+class DeviceMetricer:
+    """`OVCOSMetricer` (recorder/ovcos_metricer.py:257-307) with the pixel passes on the GPU.
+
+    `step_batch` queues the counter kernels and keeps the results on the device; nothing is copied back until
+    `show()` / `get_step_results()`."""
+
+    suppoted_metrics = sorted(SUPPORTED)
+
+    def __init__(self, class_names: Sequence[str], metric_names: Sequence[str] = ("sm", "mae", "fm", "em", "iou")):
+        self.class_names = list(class_names)
+        metric_names = tuple(metric_names) if metric_names else SUPPORTED
+        if "wfm" in metric_names:
+            raise NotImplementedError("wfm needs a distance transform over the mask; it is outside the device tail "
+                                      "(DESIGN.md §8) -- pass metric_names without 'wfm'")
+        assert set(metric_names).issubset(SUPPORTED), f"Only support: {self.suppoted_metrics}"
+        self.metric_names = metric_names
+        self._pending: List[tuple] = []
+        self._steps: List[Dict[str, object]] = []
+
+    def step_batch(self, logits: torch.Tensor, gts: Sequence[torch.Tensor], same_class) -> List[torch.Tensor]:
+        """logits (B,1,H,W) f32 mask logits; gts: B uint8 (h_i,w_i) device tensors (ragged sizes allowed);
+        same_class: B bools or a bool tensor (predicted class == ground-truth class).  Returns the uint8 masks."""
+        flags = same_class.tolist() if isinstance(same_class, torch.Tensor) else list(same_class)
+        masks = []
+        for i, gt in enumerate(gts):
+            h, w = int(gt.shape[-2]), int(gt.shape[-1])
+            pre = mask_to_u8(logits[i:i + 1], h, w)
+            self.step(pre[0], gt, bool(flags[i]))
+            masks.append(pre[0])
+        return masks
+
+    def step(self, pre: torch.Tensor, gt: torch.Tensor, same_class: bool = True, gt_path: Optional[str] = None):
+        """pre / gt uint8 (h,w) device tensors (ovcos_metricer.py:269-272 takes numpy arrays and two class names)."""
+        assert pre.shape == gt.shape, (tuple(pre.shape), tuple(gt.shape), gt_path)
+        assert pre.dtype == gt.dtype == torch.uint8, (pre.dtype, gt.dtype, gt_path)
+        if not pre.is_cuda:
+            raise RuntimeError("DeviceMetricer.step needs GPU tensors; there is no CPU path")
+        stats, hist = mask_counts(pre.reshape(1, *pre.shape[-2:]), gt.reshape(1, *gt.shape[-2:]))
+        self._pending.append((stats, hist, int(pre.shape[-2]), int(pre.shape[-1]), bool(same_class)))
+
+    def _drain(self) -> None:
+        if not self._pending:
+            return
+        stats = torch.cat([p[0] for p in self._pending]).cpu().numpy()
+        hist = torch.cat([p[1] for p in self._pending]).cpu().numpy()
+        for i, (_, _, h, w, same) in enumerate(self._pending):
+            self._steps.append(metrics_from_counts(stats[i], hist[i], h, w, same, self.metric_names))
+        self._pending = []
+
+    def get_step_results(self) -> dict:
+        return self._get_raw_results()
+
+    def _get_raw_results(self) -> dict:
+        self._drain()
+        res: Dict[str, float] = OrderedDict()
+        for m in self.metric_names:
+            if m in CURVE_METRICS:
+                curve = np.stack([np.asarray(s[f"{m}_curve"], dtype=np.float64) for s in self._steps]).mean(axis=0)
+                res[f"adp{m}"] = np.float64(np.mean([s[f"{m}_adp"] for s in self._steps]))
+                res[f"max{m}"] = np.float64(curve.max())
+                res[f"avg{m}"] = np.float64(curve.mean())
+            else:
+                res[m] = np.float64(np.mean([s[m] for s in self._steps]))
+        return res
+
+    def show(self, num_bits: Optional[int] = 3) -> dict:
+        res = self._get_raw_results()
+        if isinstance(num_bits, int):
+            res = {k: v.round(num_bits) for k, v in res.items()}
+        return {k: float(v) for k, v in res.items()}
+
+
+class DeviceClassification:
+    """`Classification` (recorder/new_evaluator.py:23-100) with the counters kept on the device."""
+
+    def __init__(self, lab2cname=None, per_class_result: bool = False, device: str = "cuda"):
+        self._lab2cname = lab2cname
+        self._per_class = per_class_result
+        self._device = torch.device(device)
+        self.reset()
+
+    def reset(self) -> None:
+        self._counters = torch.zeros(3, dtype=torch.int32, device=self._device)
+        self._pred: List[torch.Tensor] = []
+        self._true: List[torch.Tensor] = []
+
+    def process(self, mo: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+        """mo (B,C) scores, gt (B,) labels -> predicted class per row (int32, device)."""
+        if not mo.is_cuda:
+            raise RuntimeError("DeviceClassification.process needs GPU tensors; there is no CPU path")
+        scores = mo.float().contiguous()
+        labels = gt.to(device=mo.device, dtype=torch.int32).contiguous()
+        pred = torch.empty(scores.shape[0], dtype=torch.int32, device=mo.device)
+        hip.topk_accumulate(scores, labels, pred, self._counters)
+        self._pred.append(pred)
+        self._true.append(labels)
+        return pred
+
+    def evaluate(self) -> "OrderedDict[str, float]":
+        c1, c5, total = (int(v) for v in self._counters.cpu().tolist())
+        res: "OrderedDict[str, float]" = OrderedDict()
+        acc = 100.0 * c1 / total
+        res["accuracy"], res["error_rate"], res["top5"] = acc, 100.0 - acc, 100.0 * c5 / total
+        y_true = torch.cat(self._true).cpu().numpy()
+        y_pred = torch.cat(self._pred).cpu().numpy()
+        f1s = []
+        for c in np.unique(y_true):                      # macro F1 over the labels present (new_evaluator.py:72-77)
+            tp = int(((y_pred == c) & (y_true == c)).sum())
+            fp = int(((y_pred == c) & (y_true != c)).sum())
+            fn = int(((y_pred != c) & (y_true == c)).sum())
+            f1s.append(0.0 if 2 * tp + fp + fn == 0 else 2 * tp / (2 * tp + fp + fn))
+        res["macro_f1"] = 100.0 * float(np.mean(f1s))
+        if self._per_class:                              # mean of the per-class accuracies (new_evaluator.py:99-120)
+            res["perclass_accuracy"] = float(np.mean([100.0 * float((y_pred[y_true == c] == c).mean())
+                                                      for c in np.unique(y_true)]))
+        return res

@@ -22,6 +22,7 @@ EXPORTS = [
     "cvlm_patchify", "cvlm_im2col3x3", "cvlm_reinterpret_transpose", "cvlm_attention", "cvlm_small_attention",
     "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
+    "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_topk_accumulate",
 ]
 
 
@@ -292,3 +293,33 @@ def u8_to_tensor(src: torch.Tensor, top: int, left: int, ch: int, cw: int, mean:
                                     C.c_int32(top), C.c_int32(left), C.c_int32(ch), C.c_int32(cw),
                                     C.c_void_p(mean.data_ptr()), C.c_void_p(std.data_ptr()), C.c_void_p(dst.data_ptr()),
                                     C.c_void_p(_stream())), "cvlm_u8_to_tensor")
+
+
+def mask_to_u8(logits: torch.Tensor, h: int, w: int, dst: torch.Tensor) -> None:
+    """logits f32 [N][Hs][Ws] -> dst uint8 [N][h][w]: sigmoid, cv2-style bilinear resize, * 255, truncate."""
+    N, Hs, Ws = logits.shape
+    assert logits.dtype == torch.float32 and dst.dtype == torch.uint8 and tuple(dst.shape) == (N, h, w)
+    assert logits.is_contiguous() and dst.is_contiguous()
+    _check(load().cvlm_mask_to_u8(C.c_void_p(logits.data_ptr()), C.c_int32(N), C.c_int32(Hs), C.c_int32(Ws), C.c_int32(h),
+                                  C.c_int32(w), C.c_void_p(dst.data_ptr()), C.c_void_p(_stream())), "cvlm_mask_to_u8")
+
+
+def mask_joint_hist(pre: torch.Tensor, gt: torch.Tensor, stats: torch.Tensor, hist: torch.Tensor) -> None:
+    """pre/gt uint8 [N][h][w] -> stats int64 [N][3], hist int32 [N][4][2][256] (both overwritten)."""
+    N, h, w = pre.shape
+    assert pre.dtype == torch.uint8 and gt.dtype == torch.uint8 and tuple(gt.shape) == (N, h, w)
+    assert stats.dtype == torch.int64 and tuple(stats.shape) == (N, 3) and hist.dtype == torch.int32
+    assert tuple(hist.shape) == (N, 4, 2, 256) and pre.is_contiguous() and gt.is_contiguous()
+    _check(load().cvlm_mask_joint_hist(C.c_void_p(pre.data_ptr()), C.c_void_p(gt.data_ptr()), C.c_int32(N), C.c_int32(h),
+                                       C.c_int32(w), C.c_void_p(stats.data_ptr()), C.c_void_p(hist.data_ptr()),
+                                       C.c_void_p(_stream())), "cvlm_mask_joint_hist")
+
+
+def topk_accumulate(scores: torch.Tensor, labels: torch.Tensor, pred: Optional[torch.Tensor], counters: torch.Tensor) -> None:
+    """scores f32 [B][C], labels int32 [B] -> pred int32 [B]; counters int32 [3] += (top-1, top-5, rows)."""
+    B, Cc = scores.shape
+    assert scores.dtype == torch.float32 and labels.dtype == torch.int32 and counters.dtype == torch.int32
+    assert scores.is_contiguous() and labels.numel() == B and counters.numel() == 3
+    _check(load().cvlm_topk_accumulate(C.c_void_p(scores.data_ptr()), C.c_void_p(labels.data_ptr()), C.c_int32(B),
+                                       C.c_int32(Cc), C.c_void_p(_p(pred)), C.c_void_p(counters.data_ptr()),
+                                       C.c_void_p(_stream())), "cvlm_topk_accumulate")

@@ -178,6 +178,23 @@ int cvlm_resample_u8(const uint8_t* src, int32_t N, int32_t H, int32_t W, int32_
 int cvlm_u8_to_tensor(const uint8_t* src, int32_t N, int32_t H, int32_t W, int32_t C, int32_t top, int32_t left,
                       int32_t ch, int32_t cw, const float* mean, const float* stdv, float* dst, void* stream);
 
+/* ---- evaluation tail ----------------------------------------------------------------------------
+ * Replaces `torch.sigmoid` + `.cpu().numpy()` + cv2 `resize` + `(pred * 255).astype(np.uint8)`
+ * (test_ovcos_maskdecoder_edge.py:103,116-130): logits f32 [N][Hs][Ws] -> uint8 [N][h][w]. */
+int cvlm_mask_to_u8(const float* logits, int32_t N, int32_t Hs, int32_t Ws, int32_t h, int32_t w, uint8_t* dst, void* stream);
+
+/* Replaces the per-pixel numpy passes of OVCOSMetricer.step (recorder/ovcos_metricer.py:8-180, pysodmetrics 1.4.2):
+ * pre/gt uint8 [N][h][w] -> stats u64 [N][3] = (count, sum x, sum y) of gt > 128 and
+ * hist u32 [N][4][2][256] = per S-measure quadrant (LT, RT, LB, RB around the gt centroid), per gt class, per level.
+ * Both outputs are zeroed by the call.  MAE / F / E / S measures and IoU are functions of these counters alone. */
+int cvlm_mask_joint_hist(const uint8_t* pre, const uint8_t* gt, int32_t N, int32_t h, int32_t w, uint64_t* stats, uint32_t* hist,
+                         void* stream);
+
+/* Replaces Classification.process (recorder/new_evaluator.py:47-59): scores f32 [B][C], labels i32 [B] ->
+ * pred i32 [B] (may be NULL) and counters u32 [3] += (top-1 hits, top-5 hits, rows).  Counters are NOT zeroed. */
+int cvlm_topk_accumulate(const float* scores, const int32_t* labels, int32_t B, int32_t C, int32_t* pred, uint32_t* counters,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif
