@@ -17,6 +17,7 @@
 //
 // split == 3: acc += Whi.Ahi + Wlo.Ahi + Whi.Alo  (fp32 accumulate; ~2^-22 relative products)
 // split == 1: acc += Whi.Ahi
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/cvlm.h"
@@ -34,6 +35,7 @@ struct GemmParams {
     int group_m;       // tile rows per L2 super-tile (consecutive ids walk group_m x nbx tiles column-major)
     int stagger;       // first-round start offset per XCD in units of 64 cycles (0 = off): de-phases the XCDs so
                        // their epilogue store bursts do not all hit HBM at the same moment
+    unsigned long long* trace;   // DBG == 4 only: 8 x u64 per workgroup (timeline probe, tools/trace_gemm.py)
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -57,13 +59,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     const cvlm_gemm_args& g = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
+    if (DBG == 4) tr0 = wall_clock64();
 
     // ---- tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
     const int ntiles = p.nbx * p.nby;
     int pid = blockIdx.x;
     if (p.stagger > 0 && blockIdx.x < 256) {
-        const int xcd = __builtin_amdgcn_readfirstlane(blockIdx.x & 7);
-        for (int i = 0; i < xcd * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+        // slot of this workgroup's CU within its XCD (round-robin dispatch): de-phase the CUs that share one XCD
+        const int slot = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) & 31);
+        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
     }
     {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = pid & 7, idx = pid >> 3;
@@ -370,6 +375,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         issue(0, 0);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if (DBG == 4) tr1 = wall_clock64();
         if (grpB) {
             if (nk > 1) issue(1, 1);
             __builtin_amdgcn_s_barrier();                        // B starts one phase late
@@ -408,6 +414,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         }
     }
 
+    if (DBG == 4) tr2 = wall_clock64();
+    auto trace_end = [&]() {
+        if (DBG == 4 && p.trace && tid == 0) {
+            const unsigned long long t3 = wall_clock64();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t4 = wall_clock64();
+            unsigned long long* o = p.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+            o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = t3; o[4] = t4;
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+            o[6] = tr3; o[7] = tr4;
+        }
+    };
+    if (DBG == 6) {                                                  // probe: main loop only
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
     const float alpha = g.alpha;
     const bool vec_f32 = ((g.ldo & 3) == 0) && ((g.stride_o & 3) == 0);
@@ -426,79 +451,121 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     // stores (and the residual read) are whole 128- / 256-byte row segments, 16 bytes per lane.  The direct
     // store of the MFMA layout (8 bytes per lane, 32-byte row pieces) ran at 2.2 TB/s and cost 300 us on the
     // 32768 x 5120 GEMM (tools/bench_epi.py).
-    if (g.ps_c2 == 0 && (g.N & 7) == 0 && (g.hm_S == 0 || (g.hm_hd & 7) == 0) && vec_f32 && vec_res && ((g.ldoh & 7) == 0) && ((g.stride_oh & 7) == 0) && DBG != 3) {
-        constexpr int EP = 68;                                        // floats per staged row (64 + 4 pad)
-        float* ebuf = (float*)smem + wave * (16 * EP);
-        const int n0 = bn + wn * 64;
-        const int64_t zo = (int64_t)z * g.stride_o, zr = (int64_t)z * g.stride_r, zh = (int64_t)z * g.stride_oh;
+    if (g.ps_c2 == 0 && (g.N & 7) == 0 && (g.hm_S == 0 || ((g.hm_hd & 7) == 0 && g.hm_S >= WROWS)) && vec_f32 && vec_res &&
+        ((g.ldoh & 7) == 0) && ((g.stride_oh & 7) == 0)) {
+        // The activation is a compile-time constant of the body: one wave-uniform switch per tile.  (A per-value
+        // runtime switch compiled to ~8 scalar branches per output and a 240 KB epilogue that missed the
+        // instruction cache on every slab: 19 us of a 112 us tile, profiles/r01_gemm_probes.md.)
+        auto fast_epi = [&](auto act_c) {
+            constexpr int ACT = decltype(act_c)::value;
+            constexpr int EP = 68;                                    // floats per staged row (64 + 4 pad)
+            constexpr int LDS_BYTES = (NSTAGE == 6 ? 1 : (NSTAGE >= 4 ? 2 : NSTAGE)) * STAGE;
+            constexpr int NBUF = (LDS_BYTES >= NWAVE * 2 * 16 * EP * 4) ? 2 : 1;   // two slabs in flight when LDS allows
+            float* ebuf = (float*)smem + wave * (NBUF * 16 * EP);
+            const int n0 = bn + wn * 64;
+            const int64_t zo = (int64_t)z * g.stride_o, zr = (int64_t)z * g.stride_r, zh = (int64_t)z * g.stride_oh;
+            // per-lane constants of the two store shapes
+            const int rowf = lane >> 4, nf = n0 + (lane & 15) * 4;    // f32: 4 rows x 256 B per instruction
+            const int rowh = lane >> 3, nh = n0 + (lane & 7) * 8;     // h2:  8 rows x 128 B per instruction and plane
+            const int mw = bm + wm * WROWS;                           // first row of this wave
+            int64_t hm_col = 0, hm_bstride = 0;
+            int hm_b = 0, hm_t = 0;                                   // image / token of row mw + rowh
+            if (g.hm_S > 0) {                                         // head-major qkv store (8 | hd): column part once
+                const int Dh = g.hm_H * g.hm_hd;
+                const int which = nh / Dh, r2 = nh - which * Dh, h = r2 / g.hm_hd, d = r2 - h * g.hm_hd;
+                hm_bstride = (int64_t)g.hm_H * g.hm_S * g.hm_hd;
+                hm_col = (int64_t)which * (g.M / g.hm_S) * hm_bstride + (int64_t)h * g.hm_S * g.hm_hd + d;
+                hm_b = (mw + rowh) / g.hm_S;
+                hm_t = (mw + rowh) - hm_b * g.hm_S;
+            }
+            if (DBG == 4) { asm volatile("" ::"v"(bv[0][0]), "v"(bv[3][3])); tr3 = wall_clock64(); }
 #pragma clang loop unroll(full)
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m0 = bm + wm * WROWS + mt * 16;
+            for (int mt = 0; mt < MT; ++mt) {
+                if (DBG == 4 && mt == 1) tr4 = wall_clock64();
+                float* eb = ebuf + (NBUF == 2 ? (mt & 1) * (16 * EP) : 0);
+                const int m0 = mw + mt * 16;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                float v[4];
+                for (int nt = 0; nt < 4; ++nt) {
+                    float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = acc[mt][nt][j] * alpha + bv[nt][j];
-                    if (g.act != ACT_NONE && g.act != ACT_ABS_POST) v[j] = apply_act(v[j], g.act);
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[mt][nt][j] * alpha + bv[nt][j];
+                        if (ACT != ACT_NONE && ACT != ACT_ABS_POST) v[j] = apply_act(v[j], ACT);
+                    }
+                    *(float4*)(eb + fr * EP + nt * 16 + fq * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                *(float4*)(ebuf + fr * EP + nt * 16 + fq * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (g.out_f32) {                                            // 4 rows x 256 B per store instruction
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (g.out_f32) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = (lane >> 4) + 4 * i, c4 = (lane & 15) * 4;
-                    const int m = m0 + row, n = n0 + c4;
-                    float4 t = *(const float4*)(ebuf + row * EP + c4);
-                    if (m < g.M && n < g.N) {
-                        if (g.residual) {
-                            const float4 r = *(const float4*)(g.residual + zr + (int64_t)m * g.ldr + n);
-                            t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = rowf + 4 * i;
+                        const int m = m0 + row;
+                        float4 t = *(const float4*)(eb + row * EP + (lane & 15) * 4);
+                        if (m < g.M && nf < g.N) {
+                            if (g.residual) {
+                                const float4 r = *(const float4*)(g.residual + zr + (int64_t)m * g.ldr + nf);
+                                t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+                            }
+                            if (ACT == ACT_ABS_POST) { t.x = fabsf(t.x); t.y = fabsf(t.y); t.z = fabsf(t.z); t.w = fabsf(t.w); }
+                            if (DBG == 3) asm volatile("" ::"v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
+                            else *(float4*)(g.out_f32 + zo + (int64_t)m * g.ldo + nf) = t;
                         }
-                        if (g.act == ACT_ABS_POST) { t.x = fabsf(t.x); t.y = fabsf(t.y); t.z = fabsf(t.z); t.w = fabsf(t.w); }
-                        *(float4*)(g.out_f32 + zo + (int64_t)m * g.ldo + n) = t;
                     }
                 }
-            }
-            if (g.out_hi) {                                             // 8 rows x 128 B per store instruction and plane
+                if (g.out_hi) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = (lane >> 3) + 8 * i, c8 = (lane & 7) * 8;
-                    const int m = m0 + row, n = n0 + c8;
-                    const float4 t0 = *(const float4*)(ebuf + row * EP + c8);
-                    const float4 t1 = *(const float4*)(ebuf + row * EP + c8 + 4);
-                    float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                    if (m < g.M && n < g.N) {
-                        if (g.residual) {
-                            const float* r = g.residual + zr + (int64_t)m * g.ldr + n;
-                            const float4 r0 = *(const float4*)r, r1 = *(const float4*)(r + 4);
-                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-                            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                        }
-                        half8 hi, lo;
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = rowh + 8 * i;
+                        const int m = m0 + row;
+                        const float4 t0 = *(const float4*)(eb + row * EP + (lane & 7) * 8);
+                        const float4 t1 = *(const float4*)(eb + row * EP + (lane & 7) * 8 + 4);
+                        float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                        if (m < g.M && nh < g.N) {
+                            if (g.residual) {
+                                const float* r = g.residual + zr + (int64_t)m * g.ldr + nh;
+                                const float4 r0 = *(const float4*)r, r1 = *(const float4*)(r + 4);
+                                v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+                                v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                            }
+                            if (DBG == 5) {                                // probe: staging only, no split / stores
+                                asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+                                continue;
+                            }
+                            half8 hi, lo;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            float u = v[j];
-                            if (g.act == ACT_ABS_POST) u = fabsf(u);
-                            half_t a, b2;
-                            split_h2(u, a, b2);
-                            hi[j] = a; lo[j] = b2;
+                            for (int j = 0; j < 8; ++j) {
+                                float u = v[j];
+                                if (ACT == ACT_ABS_POST) u = fabsf(u);
+                                half_t a, b2;
+                                split_h2(u, a, b2);
+                                hi[j] = a; lo[j] = b2;
+                            }
+                            int64_t off = (int64_t)m * g.ldoh + nh;
+                            if (g.hm_S > 0) {                              // row part: rows advance by mt * 16 + 8 * i < hm_S
+                                int tk = hm_t + mt * 16 + 8 * i, bi = hm_b;
+                                while (tk >= g.hm_S) { tk -= g.hm_S; ++bi; }
+                                off = hm_col + (int64_t)bi * hm_bstride + (int64_t)tk * g.hm_hd;
+                            }
+                            if (DBG == 3) {                                // probe: all the work, no global stores
+                                asm volatile("" ::"v"(hi), "v"(lo), "v"(off));
+                            } else {
+                                *(half8*)((half_t*)g.out_hi + zh + off) = hi;
+                                if (g.out_lo) *(half8*)((half_t*)g.out_lo + zh + off) = lo;
+                            }
                         }
-                        int64_t off = (int64_t)m * g.ldoh + n;
-                        if (g.hm_S > 0) {                                  // head-major qkv store (8 | hd)
-                            const int Dh = g.hm_H * g.hm_hd;
-                            const int which = n / Dh, r2 = n - which * Dh, h = r2 / g.hm_hd, d = r2 - h * g.hm_hd;
-                            const int bi = m / g.hm_S, tk = m - bi * g.hm_S;
-                            off = ((((int64_t)which * (g.M / g.hm_S) + bi) * g.hm_H + h) * g.hm_S + tk) * g.hm_hd + d;
-                        }
-                        *(half8*)((half_t*)g.out_hi + zh + off) = hi;
-                        if (g.out_lo) *(half8*)((half_t*)g.out_lo + zh + off) = lo;
                     }
                 }
+                if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab fully read before it is overwritten
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // slab fully read before it is overwritten
+        };
+        switch (g.act) {
+            case ACT_GELU: fast_epi(std::integral_constant<int, ACT_GELU>{}); break;
+            case ACT_QUICKGELU: fast_epi(std::integral_constant<int, ACT_QUICKGELU>{}); break;
+            case ACT_RELU: fast_epi(std::integral_constant<int, ACT_RELU>{}); break;
+            case ACT_ABS_POST: fast_epi(std::integral_constant<int, ACT_ABS_POST>{}); break;
+            default: fast_epi(std::integral_constant<int, ACT_NONE>{}); break;
         }
+        trace_end();
         return;
     }
 #pragma clang loop unroll(full)
@@ -582,6 +649,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 
 }  // namespace
 
+static unsigned long long* g_trace = nullptr;
+// Probe hook (not part of include/cvlm.h): device buffer of 8 x u64 per workgroup for CVLM_GEMM_VARIANT=47.
+extern "C" void cvlm_debug_set_gemm_trace(void* buf) { g_trace = (unsigned long long*)buf; }
+
 extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (!args || !args->a_hi || !args->w_hi) return CVLM_E_BADARG;
     const cvlm_gemm_args& g = *args;
@@ -597,8 +668,11 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (p.a.batch <= 0) p.a.batch = 1;
     static int group_env = -1, variant_env = -1;
     if (group_env < 0) { const char* e = getenv("CVLM_GEMM_GROUP_M"); group_env = e ? atoi(e) : 8; if (group_env < 1) group_env = 1; }
-    if (variant_env < 0) { const char* e = getenv("CVLM_GEMM_VARIANT"); variant_env = e ? atoi(e) : 0; }
+    static int live_env = -1;
+    if (live_env < 0) { const char* e = getenv("CVLM_GEMM_VARIANT_LIVE"); live_env = e ? atoi(e) : 0; }
+    if (variant_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_VARIANT"); variant_env = e ? atoi(e) : 0; }
     p.group_m = group_env;
+    p.trace = g_trace;
     static int stagger_env = -1;
     if (stagger_env < 0) { const char* e = getenv("CVLM_GEMM_STAGGER"); stagger_env = e ? atoi(e) : 0; }
     p.stagger = stagger_env;
@@ -625,6 +699,13 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             // mid-size grids: 256x128 pays off on the long-M SAM shapes, 128^2 on the short CLIP ones
             const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / (g.M >= 16384 ? 1.08 : 1.05);
             variant = (c2 < c1) ? 2 : 1;
+            if (variant == 2 && g.split == 3) {
+                // long-K problems amortise the 256^2 tile's fixed cost: rounds x (us per K + fixed), fitted to
+                // tools/ab_gemm.py (256^2: 0.0685 us/K + 14 us per tile; 256x128: 0.0469 us/K)
+                const double m7 = (double)((t5 + 255) / 256) * (0.0685 * g.K + 14.0);
+                const double m2 = (double)((t2 + 255) / 256) * (0.0469 * g.K);
+                if (m7 < 0.97 * m2) variant = 5;
+            }
         }
     }
 #define CVLM_LAUNCH(SPLIT, WM, WN, NS) CVLM_LAUNCH_D(SPLIT, WM, WN, NS, 32, 0, 4)
@@ -655,6 +736,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 17) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 1, 8);
         else if (variant == 27) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 2, 8);
         else if (variant == 37) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 3, 8);        /* probe: no epilogue stores */
+        else if (variant == 57) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 5, 8);        /* probe: epilogue staging only */
+        else if (variant == 67) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 6, 8);        /* probe: main loop only */
+        else if (variant == 47 && g_trace) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 4, 8);  /* probe: per-workgroup timeline */
         else if (variant == 16) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 1, 8);
         else if (variant == 26) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 2, 8);
         else if (variant == 15) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 1, 8);
