@@ -17,6 +17,7 @@
 //
 // split == 3: acc += Whi.Ahi + Wlo.Ahi + Whi.Alo  (fp32 accumulate; ~2^-22 relative products)
 // split == 1: acc += Whi.Ahi
+#include <mutex>
 #include <type_traits>
 #include "common.h"
 #include <stdlib.h>
@@ -33,8 +34,13 @@ struct GemmParams {
     cvlm_gemm_args a;
     int nbx, nby;
     int group_m;       // tile rows per L2 super-tile (consecutive ids walk group_m x nbx tiles column-major)
-    int stagger;       // first-round start offset per XCD in units of 64 cycles (0 = off): de-phases the XCDs so
-                       // their epilogue store bursts do not all hit HBM at the same moment
+    // tail split (256^2 staggered kernel only): the last `tail_rem` tiles of a grid that does not fill its final
+    // round are cut into `tail_split` K-parts, one workgroup each; parts 0..S-2 leave f32 partial slabs in `ws`
+    // and raise `flags` (chain: part k adds part k-1's running sum), part S-1 (highest block index) runs the epilogue.
+    int tail_rem, tail_split;
+    float* ws;
+    unsigned* flags;   // [tail_rem][4] arrival words (= epoch when ready), then one error word at [4 * 128]
+    unsigned epoch;
     unsigned long long* trace;   // DBG == 4 only: 8 x u64 per workgroup (timeline probe, tools/trace_gemm.py)
 };
 
@@ -57,7 +63,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const cvlm_gemm_args& g = p.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform: tile offsets stay in SGPRs
     const int wm = wave / WN, wn = wave - wm * WN;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
     if (DBG == 4) tr0 = wall_clock64();
@@ -65,10 +72,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     // ---- tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
     const int ntiles = p.nbx * p.nby;
     int pid = blockIdx.x;
-    if (p.stagger > 0 && blockIdx.x < 256) {
-        // slot of this workgroup's CU within its XCD (round-robin dispatch): de-phase the CUs that share one XCD
-        const int slot = __builtin_amdgcn_readfirstlane((blockIdx.x >> 3) & 31);
-        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    int kpart = 0, kparts = 1, tail_j = 0;
+    if (NSTAGE == 5 && p.tail_rem > 0 && pid >= ntiles - p.tail_rem) {
+        const int j = pid - (ntiles - p.tail_rem);
+        kparts = p.tail_split;
+        kpart = j / p.tail_rem;                                      // producers first, the owner (S-1) last
+        tail_j = j - kpart * p.tail_rem;
+        pid = ntiles - p.tail_rem + tail_j;
     }
     {
         const int q = ntiles >> 3, r = ntiles & 7, xcd = pid & 7, idx = pid >> 3;
@@ -134,7 +144,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / BK;
+    int nk_ = g.K / BK;
+    if (NSTAGE == 5 && kparts > 1) {                                 // this workgroup's share of the K-tiles
+        const int base = nk_ / kparts, extra = nk_ - base * kparts;
+        const int k0 = kpart * base + (kpart < extra ? kpart : extra);
+        nk_ = base + (kpart < extra ? 1 : 0);
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) src[j] += (int64_t)k0 * BK;
+    }
+    const int nk = nk_;
     auto issue = [&](int t, int slot) {
         if (DBG == 1 && t > 1) return;                       // timing probe: no DMA in the steady state
 #pragma unroll
@@ -415,6 +433,72 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     }
 
     if (DBG == 4) tr2 = wall_clock64();
+    int m_lim = g.M;
+    if (NSTAGE == 5 && kparts > 1) {
+        // K-parts of one tile reduce along a chain: part k waits for part k-1's slab, adds it to its accumulators
+        // and (unless it is the last part, which runs the epilogue) publishes the running sum as its own slab;
+        // the order of the fp32 additions is fixed.  (Written as "owner reads all slabs | others store", two
+        // exclusive branches over the 128 accumulator registers, hipcc spilled accumulators inside the main loop.)
+        // Slabs are in accumulator layout [(wave * MT + mt) * 4 + nt][lane] float4: every store / load instruction
+        // moves one contiguous KiB.  Hand-off per MI355X_MICROARCH.md "Valid forms": storing waves drain,
+        // barrier, lane-0 agent release, drain, relaxed agent flag store; the reader polls relaxed, takes one
+        // agent acquire, drains, barrier, then plain loads.  The poll is bounded: a lost partner must not hang
+        // the device (cvlm_debug_gemm_tail_errors counts give-ups).
+        constexpr int SLAB = BM * BN;                                // floats
+        // the lane offset is made opaque here so that no slab address is computed (and kept alive) above the
+        // main loop: hoisted, those 64-bit addresses pushed the loop over its register budget
+        int lane_x = lane;
+        asm volatile("" : "+v"(lane_x));
+        if (kpart > 0) {
+            if (tid == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(&p.flags[tail_j * 4 + kpart - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) { atomicAdd(&p.flags[4 * 128], 1u); break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            const float4* slab = (const float4*)(p.ws + ((size_t)tail_j * 3 + kpart - 1) * SLAB) + (size_t)wave * MT * 4 * 64 + lane_x;
+            float4 buf[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) buf[0][nt] = slab[nt * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt + 1 < MT) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) buf[(mt + 1) & 1][nt] = slab[((mt + 1) * 4 + nt) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float4 v = buf[mt & 1][nt];
+                    acc[mt][nt][0] += v.x; acc[mt][nt][1] += v.y; acc[mt][nt][2] += v.z; acc[mt][nt][3] += v.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (kpart < kparts - 1) {
+            float4* slab = (float4*)(p.ws + ((size_t)tail_j * 3 + kpart) * SLAB) + (size_t)wave * MT * 4 * 64;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const floatx4 c = acc[mt][nt];
+                    slab[(mt * 4 + nt) * 64 + lane_x] = make_float4(c[0], c[1], c[2], c[3]);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&p.flags[tail_j * 4 + kpart], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            m_lim = 0;
+        }
+    }
     auto trace_end = [&]() {
         if (DBG == 4 && p.trace && tid == 0) {
             const unsigned long long t3 = wall_clock64();
@@ -501,7 +585,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         const int row = rowf + 4 * i;
                         const int m = m0 + row;
                         float4 t = *(const float4*)(eb + row * EP + (lane & 15) * 4);
-                        if (m < g.M && nf < g.N) {
+                        if (m < m_lim && nf < g.N) {
                             if (g.residual) {
                                 const float4 r = *(const float4*)(g.residual + zr + (int64_t)m * g.ldr + nf);
                                 t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
@@ -520,7 +604,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         const float4 t0 = *(const float4*)(eb + row * EP + (lane & 7) * 8);
                         const float4 t1 = *(const float4*)(eb + row * EP + (lane & 7) * 8 + 4);
                         float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                        if (m < g.M && nh < g.N) {
+                        if (m < m_lim && nh < g.N) {
                             if (g.residual) {
                                 const float* r = g.residual + zr + (int64_t)m * g.ldr + nh;
                                 const float4 r0 = *(const float4*)r, r1 = *(const float4*)(r + 4);
@@ -571,7 +655,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < MT; ++mt) {
         const int m = bm + wm * WROWS + mt * 16 + fr;
-        if (m >= g.M) continue;
+        if (m >= m_lim) continue;
         int64_t ps_base = 0;
         if (g.ps_c2 > 0) {
             const int x = m % g.ps_w, t = m / g.ps_w;
@@ -649,6 +733,54 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 
 }  // namespace
 
+// Modelled time of a tail round cut into S chained K-parts: one part's main loop + epilogue, first slab
+// publish (~16 us), last read-back (~8 us), ~20 us per middle hop (read + publish).
+static double tail_us(int S, int K) { return 0.0685 * K / S + 14.0 + 16.0 + 8.0 + 20.0 * (S - 2); }
+// Number of K-parts for a last round of `rem` tiles (1 = leave it whole).
+static int tail_parts(int rem, int K) {
+    if (rem <= 0 || rem > 128) return 1;
+    const int smax = 256 / rem < 4 ? 256 / rem : 4;
+    int best = 1;
+    double t = 0.0685 * K + 14.0;
+    for (int S = 2; S <= smax; ++S)
+        if (K / 32 >= 4 * S && tail_us(S, K) < t) { t = tail_us(S, K); best = S; }
+    return best;
+}
+
+// ---- tail-split workspaces: one per stream (launches on one stream are ordered, so one slab set per stream is enough)
+struct TailWs { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
+static TailWs g_tail[8];
+static int g_tail_n = 0;
+static std::mutex g_tail_mu;
+constexpr size_t TAIL_WS_BYTES = (size_t)128 * 3 * 256 * 256 * sizeof(float);
+constexpr size_t TAIL_FLAG_WORDS = 4 * 128 + 1;
+
+static TailWs* tail_workspace(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    for (int i = 0; i < g_tail_n; ++i)
+        if (g_tail[i].stream == st) return &g_tail[i];
+    if (g_tail_n == 8) return nullptr;
+    TailWs w{st, nullptr, nullptr, 0};
+    if (hipMalloc((void**)&w.ws, TAIL_WS_BYTES) != hipSuccess) return nullptr;
+    if (hipMalloc((void**)&w.flags, TAIL_FLAG_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(w.ws); return nullptr; }
+    if (hipMemset(w.flags, 0, TAIL_FLAG_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(w.ws); (void)hipFree(w.flags); return nullptr; }
+    g_tail[g_tail_n] = w;
+    return &g_tail[g_tail_n++];
+}
+
+// Probe hook (not part of include/cvlm.h): synchronises and returns how many tail owners gave up waiting for a partner.
+extern "C" int cvlm_debug_gemm_tail_errors(void) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned total = 0;
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    for (int i = 0; i < g_tail_n; ++i) {
+        unsigned e = 0;
+        if (hipMemcpy(&e, g_tail[i].flags + 4 * 128, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        total += e;
+    }
+    return (int)total;
+}
+
 static unsigned long long* g_trace = nullptr;
 // Probe hook (not part of include/cvlm.h): device buffer of 8 x u64 per workgroup for CVLM_GEMM_VARIANT=47.
 extern "C" void cvlm_debug_set_gemm_trace(void* buf) { g_trace = (unsigned long long*)buf; }
@@ -668,14 +800,13 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (p.a.batch <= 0) p.a.batch = 1;
     static int group_env = -1, variant_env = -1;
     if (group_env < 0) { const char* e = getenv("CVLM_GEMM_GROUP_M"); group_env = e ? atoi(e) : 8; if (group_env < 1) group_env = 1; }
-    static int live_env = -1;
-    if (live_env < 0) { const char* e = getenv("CVLM_GEMM_VARIANT_LIVE"); live_env = e ? atoi(e) : 0; }
+    static int live_env = -1, tail_env = -1;
+    if (tail_env < 0 || live_env > 0) { const char* e = getenv("CVLM_GEMM_TAIL"); tail_env = e ? atoi(e) : 1; }
+    { const char* e = getenv("CVLM_GEMM_VARIANT_LIVE"); live_env = e ? atoi(e) : 0; }   // probes / tests: re-read the knobs per call
     if (variant_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_VARIANT"); variant_env = e ? atoi(e) : 0; }
     p.group_m = group_env;
     p.trace = g_trace;
-    static int stagger_env = -1;
-    if (stagger_env < 0) { const char* e = getenv("CVLM_GEMM_STAGGER"); stagger_env = e ? atoi(e) : 0; }
-    p.stagger = stagger_env;
+    p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr; p.epoch = 0;
     hipStream_t s = (hipStream_t)stream;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
     int variant = variant_env;
@@ -690,22 +821,30 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         const long t2 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * p.a.batch;
         const double c1 = (double)(((t1 + 511) / 512) * 512) * 1.0;
         (void)e5; (void)e1;
-        if (t5 >= 200 && t5 <= 256) variant = 5;                                  // one full wave of 256^2 tiles
+        if (g.split == 3) {
+            // microsecond model fitted to tools/ab_gemm.py (B = 8 cascade shapes): rounds x time per tile,
+            //   128^2 (2 workgroups/CU): 0.0544 us per K;  256x128: 0.0469 us per K;
+            //   256^2 staggered: 0.0685 us per K + 14 us per tile, last partial round cut into S K-parts (tail_us).
+            const double K = (double)g.K;
+            const double m1 = (double)((t1 + 511) / 512) * 0.0544 * K;
+            const double m2 = (double)((t2 + 255) / 256) * 0.0469 * K;
+            const double tile = 0.0685 * K + 14.0;
+            const int rem = (int)(t5 % 256);
+            double tail = rem > 0 ? tile : 0.0;
+            if (tail_env && p.a.batch == 1) {
+                const int S = tail_parts(rem, g.K);
+                if (S >= 2) tail = tail_us(S, g.K);
+            }
+            const double m7 = (double)(t5 / 256) * tile + tail;
+            variant = (m7 <= m1 && m7 <= m2) ? 5 : (m2 <= m1 ? 2 : 1);
+        } else if (t5 >= 200 && t5 <= 256) variant = 5;                          // one full wave of 256^2 tiles
         else if (t5 >= 1536) {
             const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / 1.08;
             const double c5 = (double)(((t5 + 255) / 256) * 256) * 4.0 / 1.20;
             variant = (c5 <= c2 && c5 <= c1) ? 5 : (c2 <= c1 ? 2 : 1);
         } else {
-            // mid-size grids: 256x128 pays off on the long-M SAM shapes, 128^2 on the short CLIP ones
             const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / (g.M >= 16384 ? 1.08 : 1.05);
             variant = (c2 < c1) ? 2 : 1;
-            if (variant == 2 && g.split == 3) {
-                // long-K problems amortise the 256^2 tile's fixed cost: rounds x (us per K + fixed), fitted to
-                // tools/ab_gemm.py (256^2: 0.0685 us/K + 14 us per tile; 256x128: 0.0469 us/K)
-                const double m7 = (double)((t5 + 255) / 256) * (0.0685 * g.K + 14.0);
-                const double m2 = (double)((t2 + 255) / 256) * (0.0469 * g.K);
-                if (m7 < 0.97 * m2) variant = 5;
-            }
         }
     }
 #define CVLM_LAUNCH(SPLIT, WM, WN, NS) CVLM_LAUNCH_D(SPLIT, WM, WN, NS, 32, 0, 4)
@@ -721,10 +860,23 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_); \
             attr_ = true;                                                                                     \
         }                                                                                                     \
-        hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby, p.a.batch), dim3(WM* WN * 64), smem_, s, p);             \
+        hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby + extra_blocks, p.a.batch), dim3(WM* WN * 64), smem_, s, p); \
     } while (0)
+    int extra_blocks = 0;
     if (g.split == 3) {
         if (variant == 5 && variant_env == 0) variant = 7;      // auto: staggered wave groups (3-5 % over the plain 256^2 loop)
+        if (variant == 7 && tail_env && p.a.batch == 1) {
+            const long T = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+            const int rem = (int)(T % 256);
+            const int S = tail_parts(rem, g.K);
+            if (S >= 2) {
+                TailWs* w = tail_workspace(s);
+                if (w) {
+                    p.tail_rem = rem; p.tail_split = S; p.ws = w->ws; p.flags = w->flags; p.epoch = ++w->epoch;
+                    extra_blocks = rem * (S - 1);
+                }
+            }
+        }
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
         else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
         else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */

@@ -94,6 +94,41 @@ def test_gemm_pixel_shuffle(hip):
     assert relerr(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,why", [
+    (512, 768, 512, "6 tiles -> 4 K-parts each"),
+    (700, 1000, 1024, "ragged 3 x 4 tiles -> 4 parts, clamped rows / columns"),
+    (4648, 1024, 4096, "CLIP c_proj: 76 tiles -> 3 parts"),
+    (256 * 33, 256 * 8, 256, "264 tiles: one full round + 8 tail tiles cut in 2 (K-tiles: 8)"),
+    (39200, 1280, 1280, "window-block proj: 770 tiles = 3 rounds + 2 tiles in 4 parts, chip fully loaded"),
+])
+def test_gemm_tail_split(hip, M, N, K, why, monkeypatch):
+    """256^2 kernel with its last partial round cut along K: partial slabs handed between workgroups
+    (possibly across XCDs) must be complete and fresh, whichever order the partners finish in."""
+    import ctypes
+    monkeypatch.setenv("CVLM_GEMM_VARIANT_LIVE", "1")
+    monkeypatch.setenv("CVLM_GEMM_VARIANT", "7")
+    monkeypatch.setenv("CVLM_GEMM_TAIL", "1")
+    a, w, bias = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=0.05), rnd(N, seed=63)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    ref = A.float().double() @ W.float().double().t() + bias.cuda().double()            # on the GPU: 39200-row case
+    outs = []
+    for rep in range(3):                                                               # epochs advance, slabs are reused
+        out = torch.full((M, N), float("nan"), device="cuda")
+        oh = hip.H2.empty(M, N)
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=out, out_h2=oh)
+        outs.append(out)
+        assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6, why
+        assert float((oh.float().double() - ref).abs().max() / ref.abs().max()) < 2e-6, why
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])             # fixed summation order
+    monkeypatch.setenv("CVLM_GEMM_TAIL", "0")
+    plain = torch.empty(M, N, device="cuda")
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=plain)
+    assert float((plain - outs[0]).abs().max() / ref.abs().max()) < 4e-6               # same values up to fp32 sum order
+    lib = hip.load()
+    lib.cvlm_debug_gemm_tail_errors.restype = ctypes.c_int
+    assert lib.cvlm_debug_gemm_tail_errors() == 0
+
+
 def to_head_major(qkv, Bn, S, Hh, hd):
     """[B*S][3][H][hd] -> [3][B][H][S][hd] flattened back to the same (B*S, 3*H*hd) buffer shape."""
     return qkv.reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).contiguous().reshape(Bn * S, 3 * Hh * hd)

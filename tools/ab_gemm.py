@@ -5,8 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CVLM_GEMM_VARIANT_LIVE"] = "1"
 from camouflaged_vlm_amd import hip
 hip.load()
-variants = [int(v) for v in sys.argv[1:]] or [7]
+variants = [v for v in sys.argv[1:]] or ["7"]       # "7" or "7:0" (variant:CVLM_GEMM_TAIL)
 shapes = [("sam qkv", 32768, 3840, 1280), ("sam proj", 32768, 1280, 1280), ("sam lin1", 32768, 5120, 1280), ("sam lin2", 32768, 1280, 5120)]
+if os.environ.get("SHAPES") == "win":          # window blocks: 8 images x 25 windows x 196 tokens
+    shapes = [("win qkv", 39200, 3840, 1280), ("win proj", 39200, 1280, 1280), ("win lin1", 39200, 5120, 1280), ("win lin2", 39200, 1280, 5120)]
+if os.environ.get("SHAPES") == "clip":
+    shapes = [("clip in", 4648, 3072, 1024), ("clip out", 4648, 1024, 1024), ("clip fc", 4648, 4096, 1024), ("clip pj", 4648, 1024, 4096)]
 for name, M, N, K in shapes:
     a = hip.H2(torch.randn(2, M, K, device="cuda").half())
     w = hip.H2(torch.randn(2, N, K, device="cuda").half())
@@ -14,7 +18,8 @@ for name, M, N, K in shapes:
     res = {v: [] for v in variants}
     for rep in range(3):
         for v in variants:
-            os.environ["CVLM_GEMM_VARIANT"] = str(v)
+            os.environ["CVLM_GEMM_VARIANT"] = v.split(":")[0]
+            os.environ["CVLM_GEMM_TAIL"] = v.split(":")[1] if ":" in v else "1"
             hip.gemm(a, w, M, N, K, out_h2=out, split=3)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -22,4 +27,4 @@ for name, M, N, K in shapes:
                 hip.gemm(a, w, M, N, K, out_h2=out, split=3)
             e1.record(); torch.cuda.synchronize()
             res[v].append(e0.elapsed_time(e1) * 100)
-    print(f"{name:9s} " + "  ".join(f"v{v}: {min(r):7.1f} us" for v, r in res.items()), flush=True)
+    print(f"sam {name:9s} " + "  ".join(f"v{v}: {min(r):7.1f} us" for v, r in res.items()), flush=True)
