@@ -3,8 +3,10 @@
 //
 // Two workgroups of 4 waves x 32 queries (128 + 68 of the 196 queries; 2 workgroups/CU at <= 256 VGPRs)
 // per (image, window, head); K/V of the whole window
-// stream through LDS in seven 32-slot tiles as in attention.hip (query on the lane for S^T and O^T,
-// pad tokens = qkv bias rows, not stored).  What differs is the bias: instead of gathering
+// stream through LDS in seven 32-slot tiles (query on the lane for S^T and O^T, pad tokens = qkv bias
+// rows, not stored).  The tiles arrive by LDS-DMA into a two-slot ring, one tile ahead of the MFMAs and
+// with one barrier per tile: with register staging and two barriers the loop ran at the latency of a
+// global load per tile (31 us per workgroup for 9 us of MFMA work).  What differs is the bias: instead of gathering
 // Th[q][kh] + Tw[q][kw] per score element (index math + two LDS reads per element made the generic
 // kernel VALU-bound), the bias is folded into the QK^T contraction:
 //     Q_aug = [ q (80) | Th[q][0..13]/scale | Tw[q][0..13]/scale | 0 0 0 0 ]      (112 = 7 k-steps of 16)
@@ -25,26 +27,33 @@ __device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
     return __builtin_bit_cast(half4, r);
 }
 
+// timeline probe (tools/trace_attn_win.py): 4 x u64 per workgroup when set
+__device__ unsigned long long* g_win_trace = nullptr;
+
 template <int SQK, int SPV>
 __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args g, const int nwx) {
-    constexpr int HD = 80, KS = 5, ND = 3, CPR = 10, KP = 88, VP = 96, NT = 256, L = 14, S_SEQ = 196;
+    constexpr int HD = 80, KS = 5, ND = 3, CPR = 10, KP = 88, VP = 96, L = 14, S_SEQ = 196;
     constexpr int OP = 40;                                    // one-hot row pitch (halves): 5 chunks, odd
     constexpr int NPL = (SQK == 3 || SPV == 3) ? 2 : 1;
     constexpr int KT = 32, NKT = 7;                           // 7 x 32 = 224 >= 196 key slots
     constexpr int KPLANE = KT * KP, VPLANE = KT * VP;
-    constexpr int UNITS = 2 * NPL * KT * CPR;
-    constexpr int UPT = (UNITS + NT - 1) / NT;
+    constexpr int DMA_PER_WAVE = 3 * NPL;                      // 12 * NPL one-KiB instructions per tile over 4 waves
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    half_t* Ks = (half_t*)smem;                               // [NPL][KT][KP]
-    half_t* Vs = Ks + NPL * KPLANE;                           // [NPL][KT][VP]
-    constexpr int KVB = NPL * (KPLANE + VPLANE) * 2 + 128;    // K/V bytes (+ slack for the padded d tile)
-    constexpr int REGION = KVB > 128 * 33 * 4 ? KVB : 128 * 33 * 4;
-    half_t* OH = (half_t*)(smem + REGION);                    // [224][OP] one-hot(kh) | one-hot(kw)
-    int* rowoff = (int*)(OH + 224 * OP);                      // [KT]
-    float* Taug = (float*)smem;                               // prologue only, aliases K/V: [128][33]
+    // slot image (bytes): K planes at pl * 6144 (32 rows x 176 B, padded to six 1-KiB DMA instructions),
+    // V planes at NPL * 6144 + pl * 6144 (32 rows x 192 B)
+    constexpr int PLANE_B = 6144, SLOT_B = 2 * NPL * PLANE_B;
+    static_assert(KPLANE * 2 <= PLANE_B && VPLANE * 2 == PLANE_B, "plane images");
+    constexpr int TAUG_B = 128 * 33 * 4, TAIL_OFF = 2 * SLOT_B + 224 * OP * 2 + 224 * 8;
+    constexpr int TAUG_OFF = TAUG_B <= SLOT_B ? SLOT_B : TAIL_OFF;   // aliases slot 1 when it fits, else its own region
+    half_t* OH = (half_t*)(smem + 2 * SLOT_B);                // [224][OP] one-hot(kh) | one-hot(kw)
+    long long* tokoff = (long long*)(OH + 224 * OP);          // [224] K-row element offset (>= 0: qkv, < 0: -(1 + pad offset))
+    float* Taug = (float*)(smem + TAUG_OFF);                  // prologue only: [128][33]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long* const trace = g_win_trace;
+    const unsigned long long tr0 = trace ? wall_clock64() : 0;
+    unsigned long long tr1 = 0, tr2 = 0, ta = 0, tb_ = 0, tc = 0, td = 0;
     const int qc = lane & 31, half = lane >> 5;
     const int head = blockIdx.y, seq = blockIdx.z;
     const int D = g.heads * HD;
@@ -65,6 +74,27 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     const int SI = g.grid * g.grid;
     const QkvStrides QS = qkv_strides(g.qkv_layout, SI, g.B, g.heads, HD);
 
+    // ---- rel-pos table fragments (A operand of U = R . Q^T): independent of everything else, so their global
+    // loads go out first and land under the setup below
+    half8 rfh[2][KS], rfl[2][KS];
+    {
+        const int rr = qc < 27 ? qc : 26;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const half_t* Rhi = (const half_t*)(tb ? g.relw_hi : g.relh_hi);
+            const half_t* Rlo = (const half_t*)(tb ? g.relw_lo : g.relh_lo);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                rfh[tb][ks] = *(const half8*)(Rhi + rr * HD + 16 * ks + 8 * half);
+                if (SQK == 3) rfl[tb][ks] = *(const half8*)(Rlo + rr * HD + 16 * ks + 8 * half);
+            }
+        }
+    }
+    // ---- K-row offsets of the 224 key slots (slots >= 196 repeat the last key; they are masked in the softmax)
+    if (tid < 224) {
+        const int tok = token_of(tid < S_SEQ ? tid : S_SEQ - 1);
+        tokoff[tid] = tok < 0 ? -(1 + (long long)D + head * HD) : (long long)qkv_offset(QS, b, tok, 1, head);
+    }
     // ---- constant one-hot block of K_aug: one slot row per thread (224 rows, four 16-byte stores each)
     if (tid < 224) {
         const int kh = tid / L, kw = tid - kh * L;
@@ -76,6 +106,37 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
             *(half8*)(OH + tid * OP + 8 * c8) = half8{row[8 * c8], row[8 * c8 + 1], row[8 * c8 + 2], row[8 * c8 + 3],
                                                       row[8 * c8 + 4], row[8 * c8 + 5], row[8 * c8 + 6], row[8 * c8 + 7]};
     }
+
+    // ---- K/V tiles by LDS-DMA.  Instruction i of a tile (i < 12 * NPL): operand i / (6 * NPL), plane
+    // (i / 6) % NPL, sixth i % 6 of the plane image; its 64 lanes write consecutive 16-byte chunks.  A lane
+    // whose chunk is row padding (K: 11th chunk of a row, V: 11th / 12th, K image rows >= 32) re-reads chunk 0.
+    auto issue_tile = [&](int t, int slot) {
+        unsigned char* sbase = smem + slot * SLOT_B;
+        const half_t* srcs[DMA_PER_WAVE];
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) {                // all offset reads first, then the DMA instructions
+            const int i = wave * DMA_PER_WAVE + j;
+            const int op = i / (6 * NPL), pl = (i / 6) % NPL, sub = i % 6;
+            const int c = sub * 64 + lane;
+            const int cpr = op ? 12 : 11;
+            int row = c / cpr, ch = c - row * cpr;
+            if (row >= KT) row = KT - 1;
+            if (ch >= CPR) ch = 0;
+            const long long ko = tokoff[t * KT + row];
+            const bool pad = ko < 0;
+            const long long o = pad ? (-ko - 1) + (op ? D : 0) : ko + (op ? QS.sop : 0);
+            srcs[j] = (pad ? pad_hi + pl * pad_plane : qkv_hi + pl * qkv_plane) + o + ch * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) {
+            const int i = wave * DMA_PER_WAVE + j;
+            const int op = i / (6 * NPL), pl = (i / 6) % NPL, sub = i % 6;
+            glds16(srcs[j], sbase + (op * NPL + pl) * PLANE_B + sub * 1024);
+        }
+    };
+    __syncthreads();                                          // tokoff visible
+    issue_tile(0, 0);                                         // lands under the Th / Tw prologue below
+    if (trace) ta = wall_clock64();
 
     // ---- queries
     const int q0 = blockIdx.x * 128 + wave * 32;
@@ -95,28 +156,24 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
             if (SQK == 3) ql[ks] = *(const half8*)(bl + 16 * ks + 8 * half);
         }
     }
+    if (trace) { asm volatile("" ::"v"(qh[0]), "v"(qh[4])); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tb_ = wall_clock64(); }
     // ---- Th / Tw for this query: U = Q . R^T (27 rows -> one 32-row MFMA tile per table), scattered to Taug[q][..]
     {
         const int qhh = qs / L, qww = qs - qhh * L;
         float* Tq = Taug + (wave * 32 + qc) * 33;
         if (half == 0) { Tq[28] = 0.f; Tq[29] = 0.f; Tq[30] = 0.f; Tq[31] = 0.f; }
-#pragma unroll 1
+#pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
-            const half_t* Rhi = (const half_t*)(tb ? g.relw_hi : g.relh_hi);
-            const half_t* Rlo = (const half_t*)(tb ? g.relw_lo : g.relh_lo);
             const int cq = tb ? qww : qhh;
             floatx16 u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) u[r] = 0.f;
-            const int rr = qc < 27 ? qc : 26;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const half8 ah = *(const half8*)(Rhi + rr * HD + 16 * ks + 8 * half);
-                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(rfh[tb][ks], qh[ks], u, 0, 0, 0);
                 if (SQK == 3) {
-                    const half8 al = *(const half8*)(Rlo + rr * HD + 16 * ks + 8 * half);
-                    u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], u, 0, 0, 0);
-                    u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], u, 0, 0, 0);
+                    u = __builtin_amdgcn_mfma_f32_32x32x16_f16(rfl[tb][ks], qh[ks], u, 0, 0, 0);
+                    u = __builtin_amdgcn_mfma_f32_32x32x16_f16(rfh[tb][ks], ql[ks], u, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -127,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
             }
         }
     }
+    if (trace) tc = wall_clock64();
     __syncthreads();
     {
         // augmented B fragments: k-step 5 covers aug dims 0..15, k-step 6 dims 16..31; lane holds dims 8*half .. +8
@@ -143,51 +201,7 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
             }
     }
     __syncthreads();                                          // Taug (aliasing K/V) is dead from here on
-
-    // ---- K/V staging
-    half8 stage[UPT];
-    auto row_token = [&](int t, int row) -> int {
-        int slot = t * KT + row;
-        slot = slot < S_SEQ ? slot : S_SEQ - 1;
-        return token_of(slot);
-    };
-    auto prefetch = [&]() {
-#pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            const int u = tid + i * NT;
-            if (u < UNITS) {
-                const int chunk = u % CPR;
-                const int row = (u / CPR) % KT;
-                const int po = u / (CPR * KT);
-                const int op = po / NPL, pl = po - op * NPL;
-                const int tok = rowoff[row];
-                const int64_t ro = tok < 0 ? (int64_t)(op + 1) * D + head * HD
-                                           : qkv_offset(QS, b, tok, op + 1, head);
-                // plane / pad selection by integer arithmetic (a 4-way pointer select was turned into a
-                // stack lookup table by the compiler, i.e. scratch traffic in the staging loop)
-                const int64_t po_ = tok < 0 ? pad_plane * pl : qkv_plane * pl;
-                const half_t* base = (tok < 0 ? pad_hi : qkv_hi) + po_ + ro;
-                stage[i] = *(const half8*)(base + chunk * 8);
-            }
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < UPT; ++i) {
-            const int u = tid + i * NT;
-            if (u < UNITS) {
-                const int chunk = u % CPR;
-                const int row = (u / CPR) % KT;
-                const int po = u / (CPR * KT);
-                const int op = po / NPL, pl = po - op * NPL;
-                half_t* dst = op ? Vs + pl * VPLANE + row * VP : Ks + pl * KPLANE + row * KP;
-                *(half8*)(dst + chunk * 8) = stage[i];
-            }
-        }
-    };
-    if (tid < KT) rowoff[tid] = row_token(0, tid);
-    __syncthreads();
-    prefetch();
+    if (trace) td = wall_clock64();
 
     float m_run = -INFINITY, l_run = 0.f;
     floatx16 o[ND];
@@ -196,15 +210,17 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
     const float scale = g.scale;
+    if (trace) tr1 = wall_clock64();
     const int tg = lane >> 4, ti = lane & 15;
     const int v_lane_off = (4 * (tg >> 1) + (ti >> 2)) * VP + 16 * (tg & 1) + 4 * (ti & 3);
 
 #pragma unroll 1
     for (int t = 0; t < NKT; ++t) {
-        commit();
-        if (t + 1 < NKT && tid < KT) rowoff[tid] = row_token(t + 1, tid);
-        __syncthreads();
-        if (t + 1 < NKT) prefetch();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile t has landed
+        __syncthreads();                                      // ... everyone's has, and slot (t + 1) & 1 is free
+        if (t + 1 < NKT) issue_tile(t + 1, (t + 1) & 1);
+        const half_t* Ks = (const half_t*)(smem + (t & 1) * SLOT_B);
+        const half_t* Vs = Ks + NPL * (PLANE_B / 2);
         if (wave_active) {
             const int sub = 0;
             floatx16 s;
@@ -216,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
                 const half8 kh = *(const half8*)(kr + 16 * ks);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
                 if (SQK == 3) {
-                    const half8 kl = *(const half8*)(kr + KPLANE + 16 * ks);
+                    const half8 kl = *(const half8*)(kr + PLANE_B / 2 + 16 * ks);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
                     s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
                 }
@@ -274,8 +290,8 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
                     const half8 vh = half8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[n], 0, 0, 0);
                     if (SPV == 3) {
-                        const half4 w0 = lds_read_tr16(vb + VPLANE + 32 * n);
-                        const half4 w1 = lds_read_tr16(vb + VPLANE + 32 * n + 8 * VP);
+                        const half4 w0 = lds_read_tr16(vb + PLANE_B / 2 + 32 * n);
+                        const half4 w1 = lds_read_tr16(vb + PLANE_B / 2 + 32 * n + 8 * VP);
                         const half8 vl = half8{w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
                         o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[n], 0, 0, 0);
                         o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[n], 0, 0, 0);
@@ -283,9 +299,9 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
                 }
             }
         }
-        __syncthreads();
     }
 
+    if (trace) tr2 = wall_clock64();
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (wave_active && qvalid && qtok >= 0) {
         const float inv = 1.0f / l_tot;
@@ -306,13 +322,17 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
                 }
             }
     }
+    if (trace && tid == 0) {
+        unsigned long long* o = trace + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+        o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = wall_clock64(); o[4] = ta; o[5] = tb_; o[6] = tc; o[7] = td;
+    }
 }
 
 template <int SQK, int SPV>
 int launch_win(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int NPL = (SQK == 3 || SPV == 3) ? 2 : 1;
-    constexpr int kv = NPL * 32 * (88 + 96) * 2 + 128;
-    constexpr int smem = (kv > 128 * 33 * 4 ? kv : 128 * 33 * 4) + 224 * 40 * 2 + 32 * 4;
+    constexpr int slot = 2 * NPL * 6144, taug = 128 * 33 * 4;
+    constexpr int smem = 2 * slot + 224 * 40 * 2 + 224 * 8 + (taug <= slot ? 0 : taug);
     const int nwx = (g.grid + 13) / 14;
     auto kern = attn_win14_kernel<SQK, SPV>;
     static bool attr = false;
@@ -333,4 +353,9 @@ int cvlm_attention_window14(const cvlm_attn_args& g, hipStream_t s) {
     if (g.split_qk == 3 && g.split_pv == 1) return launch_win<3, 1>(g, s);
     if (g.split_qk == 1 && g.split_pv == 1) return launch_win<1, 1>(g, s);
     return CVLM_E_UNSUPPORTED;
+}
+
+// Probe hook (not part of include/cvlm.h).
+extern "C" int cvlm_debug_set_attn_win_trace(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_win_trace), &buf, sizeof(buf));
 }

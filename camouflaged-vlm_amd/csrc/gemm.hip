@@ -391,13 +391,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         };
         // prologue: tile 0 resident for everyone; group B also launches its share of tile 1 (its "P1(-1)")
         issue(0, 0);
-        wait_vmcnt<0>();
+        if (grpB && nk > 1) { issue(1, 1); wait_vmcnt<PER_WAVE>(); }   // B's share of tile 1 rides behind tile 0
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (DBG == 4) tr1 = wall_clock64();
-        if (grpB) {
-            if (nk > 1) issue(1, 1);
-            __builtin_amdgcn_s_barrier();                        // B starts one phase late
-        }
+        if (grpB) __builtin_amdgcn_s_barrier();                  // B starts one phase late
         for (int t = 0; t < nk; ++t) {
             const unsigned char* cur = smem + (t & 1) * STAGE;
             // ---- P0

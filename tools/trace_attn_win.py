@@ -1,0 +1,29 @@
+"""Per-workgroup timeline of the window-attention kernel (B = 8 cascade shape).  Usage: python tools/trace_attn_win.py"""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from camouflaged_vlm_amd import hip
+lib = hip.load()
+B, H, hd, G = 8, 16, 80, 64
+D, S = H * hd, G * G
+qkv = hip.H2(torch.randn(2, B * S, 3 * D, device="cuda").half())
+out = hip.H2.empty(B * S, D)
+rw = hip.H2((torch.randn(2, 27, hd, device="cuda") * 0.1).half())
+pad = hip.H2((torch.randn(2, 3 * D, device="cuda") * 0.1).half())
+fn = lambda: hip.attention(qkv, out, B, S, H, hd, mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw, split_qk=3, split_pv=3, head_major=True)
+nwg = 2 * H * B * 25
+buf = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+for _ in range(2): fn()
+torch.cuda.synchronize()
+assert lib.cvlm_debug_set_attn_win_trace(C.c_void_p(buf.data_ptr())) == 0
+fn(); torch.cuda.synchronize()
+assert lib.cvlm_debug_set_attn_win_trace(None) == 0
+t = buf.cpu().numpy().reshape(nwg, 8)
+us = lambda x: x / 100.0
+print(f"{nwg} workgroups, span {us(t[:, 3].max() - t[:, 0].min()):.1f} us")
+for half, lab in ((0, "128-query workgroups"), (1, "68-query workgroups")):
+    tt = t[half::2]
+    for name, v in (("  setup+dma0", us(tt[:, 4] - tt[:, 0])), ("  q loads", us(tt[:, 5] - tt[:, 4])), ("  U mfma+scatter", us(tt[:, 6] - tt[:, 5])),
+                    ("  sync+aug frags", us(tt[:, 7] - tt[:, 6])), ("prologue", us(tt[:, 1] - tt[:, 0])), ("7-tile loop", us(tt[:, 2] - tt[:, 1])), ("output", us(tt[:, 3] - tt[:, 2])),
+                    ("total", us(tt[:, 3] - tt[:, 0]))):
+        print(f"  {lab:22s} {name:12s} mean {v.mean():6.2f}  p10 {np.percentile(v, 10):6.2f}  p90 {np.percentile(v, 90):6.2f} us")
