@@ -223,12 +223,20 @@ __global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict_
     const float* h4 = h0 + 4 * C;
     for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < HW; pix += gridDim.x * blockDim.x) {
         const float4* u = (const float4*)(up + ((int64_t)b * HW + pix) * C);
-        const float4* e = (const float4*)(edge + ((int64_t)b * HW + pix) * C);
         float m = 0.f, g = 0.f;
         for (int c = 0; c < (C >> 2); ++c) {
-            const float4 a = u[c], d = e[c];
-            const float4 w0 = ((const float4*)h0)[c], w4 = ((const float4*)h4)[c];
+            const float4 a = u[c];
+            const float4 w0 = ((const float4*)h0)[c];
             m += a.x * w0.x + a.y * w0.y + a.z * w0.z + a.w * w0.w;
+        }
+        if (!edge) {                                             // vanilla decoder: plain hypernetwork product
+            low[(int64_t)b * HW + pix] = m;
+            continue;
+        }
+        const float4* e = (const float4*)(edge + ((int64_t)b * HW + pix) * C);
+        for (int c = 0; c < (C >> 2); ++c) {
+            const float4 d = e[c];
+            const float4 w4 = ((const float4*)h4)[c];
             g += d.x * w4.x + d.y * w4.y + d.z * w4.z + d.w * w4.w;
         }
         const float s = 1.0f / (1.0f + expf(-g));
@@ -518,7 +526,7 @@ int cvlm_dense_pe(const float* gauss, int32_t size, int32_t C, float* out, void*
 
 int cvlm_mask_head(const float* up, const float* edge_emb, const float* hyper, int32_t B, int32_t HW, int32_t C,
                    float* low, void* stream) {
-    if (!up || !edge_emb || !hyper || !low || (C & 3)) return CVLM_E_BADARG;
+    if (!up || !hyper || !low || (C & 3)) return CVLM_E_BADARG;
     hipLaunchKernelGGL(mask_head_kernel, dim3(grid_for(HW, 256, 1024), B), dim3(256), 0, (hipStream_t)stream, up,
                        edge_emb, hyper, HW, C, low);
     CVLM_CHECK_LAUNCH();

@@ -413,6 +413,138 @@ class MaskDecoder(_Base):
         return low
 
 
+class VanillaMaskDecoder(MaskDecoder):
+    """Vanilla SAM MaskDecoder of the registry entry ``sam`` (models/sam.py:322-333; mask_decoder.py:73-150,
+    transformer.py:62-107,151-183): 1 IoU + 4 mask tokens, no prompts, no condition attentions, no edge branch;
+    `multimask_output=False` keeps mask 0.  Same kernels as the edge decoder."""
+
+    NT = 5
+
+    def __init__(self, sd: Dict[str, torch.Tensor], g: SamGeometry, device, precision: Precision,
+                 prefix: str = "mask_decoder."):
+        _Base.__init__(self, device, precision)
+        self.g = g
+        P = prefix
+        self.lin, self.ln = {}, {}
+        names = {k[len(P):] for k in sd if k.startswith(P)}
+        for name in names:
+            if not name.endswith(".weight") or name in ("iou_token.weight", "mask_tokens.weight"):
+                continue
+            stem, t = name[:-7], sd[P + name]
+            if t.dim() == 2 and stem + ".bias" in names:
+                self.lin[stem] = Linear(t, sd[P + stem + ".bias"], device)
+            elif t.dim() == 1:
+                self.ln[stem] = (self.dev(t), self.dev(sd[P + stem + ".bias"]))
+        self.tokens = self.dev(torch.cat([sd[P + "iou_token.weight"], sd[P + "mask_tokens.weight"]], 0))   # (5, C)
+
+        def convT2(name):
+            w = sd[P + name + ".weight"].detach().float().cpu()
+            return Linear(w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]),
+                          sd[P + name + ".bias"].detach().float().cpu().repeat(4), device)
+
+        self.up = {"output_upscaling": (convT2("output_upscaling.0"), convT2("output_upscaling.3"))}
+        self.pe = None
+        self.heads = 8                                               # models/sam.py:328
+
+    def _attn(self, name, q, k, v, B, nq, nk, out):
+        ws, heads = self.ws, self.heads
+        I = self.lin[name + ".q_proj"].N
+        qp, kp, vp = ws.f32("a_q", B * nq, I), ws.f32("a_k", B * nk, I), ws.f32("a_v", B * nk, I)
+        self.gemm(q, self.lin[name + ".q_proj"], B * nq, out_f32=qp)
+        self.gemm(k, self.lin[name + ".k_proj"], B * nk, out_f32=kp)
+        self.gemm(v, self.lin[name + ".v_proj"], B * nk, out_f32=vp)
+        o = ws.f32("a_o", B * nq, I)
+        hip.small_attention(qp, kp, vp, o, B, nq, nk, heads, I // heads)
+        oh = ws.h2("a_oh", B * nq, I)
+        hip.split_f32(o, oh)
+        self.gemm(oh, self.lin[name + ".out_proj"], B * nq, out_f32=out)
+
+    def forward(self, feats: torch.Tensor, no_mask: torch.Tensor, gauss: torch.Tensor, B: int,
+                taps: Optional[dict] = None) -> torch.Tensor:
+        """feats f32 [B*T][C] -> low-res mask logits f32 [B][4G][4G] (mask 0)."""
+        g, ws, NT = self.g, self.ws, self.NT
+        G, C, T = g.grid, g.prompt_embed_dim, g.grid * g.grid
+        if self.pe is None:
+            self.pe = torch.empty(T, C, device=self.device)
+            hip.dense_pe(gauss, G, C, self.pe)
+        queries = ws.f32("vqueries", B * NT, C)
+        queries.view(B, NT, C).copy_(self.tokens)
+        keys = ws.f32("vkeys", B * T, C)
+        hip.add_rows(feats, no_mask, 1, B * T, C, out_f32=keys)          # src = image_embeddings + dense (mask_decoder.py:126)
+        qh, kh, vh = ws.h2("vd_q", B * NT, C), ws.h2("vd_k", B * T, C), ws.h2("vd_v", B * T, C)
+        tq, tk = ws.h2("vd_tq", B * NT, C), ws.h2("vd_tk", B * NT, C)
+        ao_q, ao_k = ws.f32("vao_q", B * NT, C), ws.f32("vao_k", B * T, C)
+        hidh = ws.h2("vd_hid", B * NT, 2048)
+        mo = ws.f32("vd_mlp", B * NT, C)
+        for i in range(2):
+            L = f"transformer.layers.{i}."
+            ln = lambda n: self.ln[L + n]
+            if i == 0:                                                    # transformer.py:157-158
+                hip.split_f32(queries, tq)
+                self._attn(L + "self_attn", tq, tq, tq, B, NT, NT, ao_q)
+                hip.layernorm(ao_q, *ln("norm1"), 1e-5, B * NT, C, out_f32=queries)
+            else:
+                hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=tq)
+                hip.split_f32(queries, tk)
+                self._attn(L + "self_attn", tq, tq, tk, B, NT, NT, ao_q)
+                hip.layernorm(queries, *ln("norm1"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries)
+            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)   # :166-170
+            hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
+            hip.split_f32(keys, vh)
+            self._attn(L + "cross_attn_token_to_image", qh, kh, vh, B, NT, T, ao_q)
+            hip.layernorm(queries, *ln("norm2"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries, out_h2=qh)
+            self.gemm(qh, self.lin[L + "mlp.lin1"], B * NT, out_h2=hidh, act=ACT_RELU)   # :173-175
+            self.gemm(hidh, self.lin[L + "mlp.lin2"], B * NT, out_f32=mo)
+            hip.layernorm(queries, *ln("norm3"), 1e-5, B * NT, C, add=mo, add_rows=B * NT, out_f32=queries)
+            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)   # :178-182
+            hip.split_f32(queries, tq)
+            self._attn(L + "cross_attn_image_to_token", kh, qh, tq, B, T, NT, ao_k)
+            hip.layernorm(keys, *ln("norm4"), 1e-5, B * T, C, add=ao_k, add_rows=B * T, out_f32=keys)
+        hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)       # :99-105
+        hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
+        hip.split_f32(keys, vh)
+        self._attn("transformer.final_attn_token_to_image", qh, kh, vh, B, NT, T, ao_q)
+        hs = ws.f32("vhs", B * NT, C)
+        hip.layernorm(queries, *self.ln["transformer.norm_final_attn"], 1e-5, B * NT, C, add=ao_q, add_rows=B * NT,
+                      out_f32=hs)
+        up = self._upscale(vh, B, G, "output_upscaling", True, ws.f32("vupscaled", B * 16 * T, C // 8))
+        HW = 16 * T
+        hyper = ws.f32("vhyper", B, 5, C // 8)                              # row 0 = mask token 0's hypernetwork output
+        row, rowh = ws.f32("vh_row", B, C), ws.h2("vh_rowh", B, C)
+        t1, t2 = ws.h2("vh_t1", B, C), ws.h2("vh_t2", B, C)
+        hip.gather_rows(hs, B, NT, C, None, 1, row)
+        hip.split_f32(row, rowh)
+        mlp = "output_hypernetworks_mlps.0"
+        self.gemm(rowh, self.lin[mlp + ".layers.0"], B, out_h2=t1, act=ACT_RELU)
+        self.gemm(t1, self.lin[mlp + ".layers.1"], B, out_h2=t2, act=ACT_RELU)
+        self.gemm(t2, self.lin[mlp + ".layers.2"], B, out_f32=hyper[:, 0], ldo=5 * (C // 8))
+        low = ws.f32("vlow", B, HW)
+        hip.mask_head(up, None, hyper, B, HW, C // 8, low)                 # plain hyper . upscaled (mask_decoder.py:139)
+        if taps is not None:
+            taps.update(hs=hs.clone(), low_res_masks=low.clone())
+        return low
+
+
+class SamPlain(_Base):
+    """Registry entry ``sam`` (models/sam.py:417-440 `infer`): encoder -> vanilla decoder -> bilinear to inp_size."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], g: SamGeometry, device, precision: Precision = Precision()):
+        super().__init__(device, precision)
+        self.g = g
+        self.encoder = SamEncoder(sd, g, device, precision)
+        self.decoder = VanillaMaskDecoder(sd, g, device, precision)
+        self.no_mask = self.dev(sd["no_mask_embed.weight"].reshape(1, -1))
+        self.gauss = self.dev(sd["pe_layer.positional_encoding_gaussian_matrix"])
+
+    def infer(self, inp: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        g, B = self.g, inp.shape[0]
+        feats = self.encoder.forward(inp, taps)
+        low = self.decoder.forward(feats, self.no_mask, self.gauss, B, taps)
+        masks = torch.empty(B, 1, g.inp_size, g.inp_size, device=self.device)
+        hip.bilinear(low, B, 4 * g.grid, 4 * g.grid, masks, g.inp_size, g.inp_size)
+        return masks
+
+
 # ================================================================================================
 # MaPLe / Alpha-CLIP  (alpha_clip_rw/model.py:507-563, cocotrainers/mapleAlphaCLIP.py:55-78,210-294)
 # ================================================================================================

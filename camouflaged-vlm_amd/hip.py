@@ -235,7 +235,7 @@ def dense_pe(gauss: torch.Tensor, size: int, Cc: int, out: torch.Tensor) -> None
 
 
 def mask_head(up, edge_emb, hyper, B: int, HW: int, Cc: int, low) -> None:
-    _check(load().cvlm_mask_head(C.c_void_p(up.data_ptr()), C.c_void_p(edge_emb.data_ptr()),
+    _check(load().cvlm_mask_head(C.c_void_p(up.data_ptr()), C.c_void_p(_p(edge_emb)),
                                  C.c_void_p(hyper.data_ptr()), C.c_int32(B), C.c_int32(HW), C.c_int32(Cc),
                                  C.c_void_p(low.data_ptr()), C.c_void_p(_stream())), "cvlm_mask_head")
 

@@ -229,6 +229,54 @@ def mask_decoder_entries(g: SamGeometry, prefix: str = "mask_decoder.") -> List[
     return e
 
 
+def vanilla_decoder_entries(g: SamGeometry, prefix: str = "mask_decoder.") -> List[Entry]:
+    """Vanilla SAM MaskDecoder of the registry entry ``sam`` (models/sam.py:322-333;
+    models/mmseg/models/sam/mask_decoder.py:17-71, transformer.py:17-60,109-150,185-204): depth 2, 8 heads,
+    mlp 2048 hard-coded, 1 IoU + 4 mask tokens, no edge branch, no condition attentions."""
+    C = g.prompt_embed_dim
+    e: List[Entry] = []
+    t = prefix + "transformer."
+    for i in range(2):
+        l = f"{t}layers.{i}."
+        _dec_attn(e, l + "self_attn", C, C)
+        _ln(e, l + "norm1", C)
+        _dec_attn(e, l + "cross_attn_token_to_image", C, C // 2)
+        _ln(e, l + "norm2", C)
+        _lin(e, l + "mlp.lin1", 2048, C)
+        _lin(e, l + "mlp.lin2", C, 2048)
+        _ln(e, l + "norm3", C)
+        _ln(e, l + "norm4", C)
+        _dec_attn(e, l + "cross_attn_image_to_token", C, C // 2)
+    _dec_attn(e, t + "final_attn_token_to_image", C, C // 2)
+    _ln(e, t + "norm_final_attn", C)
+    e.append((prefix + "iou_token.weight", (1, C), "embed"))
+    e.append((prefix + "mask_tokens.weight", (4, C), "embed"))
+    p = prefix + "output_upscaling"
+    e.append((p + ".0.weight", (C, C // 4, 2, 2), "convT"))
+    e.append((p + ".0.bias", (C // 4,), "bias"))
+    _ln(e, p + ".1", C // 4)
+    e.append((p + ".3.weight", (C // 4, C // 8, 2, 2), "convT"))
+    e.append((p + ".3.bias", (C // 8,), "bias"))
+    for i in range(4):
+        m = f"{prefix}output_hypernetworks_mlps.{i}.layers."
+        _lin(e, m + "0", C, C)
+        _lin(e, m + "1", C, C)
+        _lin(e, m + "2", C // 8, C, "hyper_tail")
+    m = prefix + "iou_prediction_head.layers."
+    _lin(e, m + "0", 256, C)
+    _lin(e, m + "1", 256, 256)
+    _lin(e, m + "2", 4, 256)
+    return e
+
+
+def sam_plain_entries(g: SamGeometry) -> List[Entry]:
+    """state_dict of the registry entry ``sam`` (models/sam.py:298-354): encoder, vanilla decoder, PE matrix,
+    no-mask embedding."""
+    C = g.prompt_embed_dim
+    return (sam_encoder_entries(g) + vanilla_decoder_entries(g) +
+            [("pe_layer.positional_encoding_gaussian_matrix", (2, C // 2), "gauss"), ("no_mask_embed.weight", (1, C), "embed")])
+
+
 def wrapper_entries(g: SamGeometry) -> List[Entry]:
     C = g.prompt_embed_dim
     e: List[Entry] = []

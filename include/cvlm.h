@@ -134,7 +134,8 @@ int cvlm_dense_pe(const float* gauss, int32_t size, int32_t C, float* out, void*
 
 /* Mask head (mask_decoder_edge.py:181-186 + models/sam_maskdecoder_edge.py:380-387):
  * up, edge_emb f32 NHWC [B][h][w][C]; hyper f32 [B][5][C] (rows 0..3 mask MLPs, row 4 edge MLP).
- * low[b][y][x] = m*sigmoid(e) + m with m = hyper[b][0].up, e = hyper[b][4].edge_emb  (mask 0 only). */
+ * low[b][y][x] = m*sigmoid(e) + m with m = hyper[b][0].up, e = hyper[b][4].edge_emb  (mask 0 only).
+ * edge_emb == NULL: low = m, the vanilla decoder's product (models/mmseg/models/sam/mask_decoder.py:139). */
 int cvlm_mask_head(const float* up, const float* edge_emb, const float* hyper, int32_t B, int32_t HW, int32_t C,
                    float* low, void* stream);
 

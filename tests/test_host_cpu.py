@@ -103,8 +103,11 @@ def test_registry_and_dropin_state_dict(tmp_path):
         m.infer_test(torch.zeros(1, 3, 320, 320), torch.zeros(1, 3, 56, 56), torch.zeros(1, 1, 56, 56))
     with pytest.raises(AssertionError):
         m.cuda if False else m.infer_test(torch.zeros(1, 3, 64, 64), None, None)   # wrong image size (image_encoder.py:375)
-    with pytest.raises(NotImplementedError):
-        models.make({"name": "sam", "args": {}})
+    # N4: the second registry name builds too (vanilla decoder), with the reference's key layout
+    plain = models.make({"name": "sam", "args": {"inp_size": 320, "loss": "iou", "encoder_mode": enc}})
+    assert set(plain.state_dict()) == {n for n, _, _ in spec.sam_plain_entries(g)}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        plain.infer(torch.zeros(1, 3, 320, 320))
 
 
 def test_demo_yaml_loads(tmp_path):

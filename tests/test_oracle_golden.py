@@ -84,3 +84,17 @@ def test_tokens_fixture(golden_dir):
         # "a photo of a owlfly larva." (measured from the reference tokenizer)
         assert tk[0, :11].tolist() == [49406, 320, 1125, 539, 320, 34332, 3228, 1592, 1892, 269, 49407]
         assert z["bank_test"].shape == (61, 768) and abs(float(np.linalg.norm(z["bank_test"][0])) - 1) < 1e-4
+
+
+def test_plain_sam_entry_matches_reference(golden_dir):
+    """N4: registry entry `sam` (vanilla MaskDecoder, no prompts) -- oracle vs the reference's `SAM.infer`."""
+    with np.load(os.path.join(golden_dir, "tiny_sam_plain.npz")) as z:
+        gp = {k: z[k] for k in z.files}
+    g = spec.TINY_SAM
+    sd = O.to_torch_sd(synth.make_state_dict(spec.sam_plain_entries(g), 0))
+    inp, _, _ = synth.make_inputs(g, spec.TINY_CLIP, 2)
+    with torch.no_grad():
+        m = O.sam_plain_infer(torch.from_numpy(inp), sd, g)
+    assert m.shape == gp["mask_logits"].shape
+    assert d(m, gp["mask_logits"]) < 2e-5
+    assert O.mask_iou(m.numpy(), gp["mask_logits"]) >= 0.9999

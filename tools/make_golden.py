@@ -218,16 +218,57 @@ def demo_digest(out_dir, mods, n_images=1):
     print("demo: %d image(s) in %.1f s; mask std %.3f; pred %s" % (n_images, dt, masks.std(), preds))
 
 
+def sam_plain(out_dir, mods):
+    """Registry entry ``sam`` (models/sam.py:298-440): encoder + vanilla MaskDecoder, no prompts -> `infer` masks."""
+    import importlib
+    mm = mods[0]
+    _stub("open_clip")
+    importlib.import_module("models.sam")
+    g = spec.TINY_SAM
+    enc = dict(name="sam", img_size=g.inp_size, mlp_ratio=g.mlp_ratio, patch_size=g.patch_size,
+               qkv_bias=True, use_rel_pos=True, window_size=g.window_size, out_chans=g.out_chans,
+               scale_factor=32, input_type="fft", freq_nums=0.25, prompt_type="highpass",
+               prompt_embed_dim=g.prompt_embed_dim, tuning_stage=1234, handcrafted_tune=True,
+               embedding_tune=True, adaptor="adaptor", embed_dim=g.embed_dim, depth=g.depth,
+               num_heads=g.num_heads, global_attn_indexes=list(g.global_attn_indexes))
+    model = mm.make({"name": "sam", "args": {"inp_size": g.inp_size, "loss": "iou", "encoder_mode": enc}})
+    sd = synth.make_state_dict(spec.sam_plain_entries(g), 0)
+    ref_keys = set(model.state_dict().keys())
+    assert ref_keys == set(sd.keys()), (sorted(ref_keys - set(sd))[:8], sorted(set(sd) - ref_keys)[:8])
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    model.eval()
+    inp, _, _ = synth.make_inputs(g, spec.TINY_CLIP, batch=2)
+    taps = {}
+    def tap(name, pick):
+        def hook(m, i, o):
+            if name not in taps:                # first image only
+                taps[name] = pick(o).detach().numpy().copy()
+        return hook
+    h1 = model.mask_decoder.transformer.register_forward_hook(tap("hs", lambda o: o[0]))
+    h2 = model.mask_decoder.register_forward_hook(tap("low_res_masks", lambda o: o[0]))
+    with torch.no_grad():
+        masks = np.concatenate([model.infer(torch.from_numpy(inp[b:b + 1])).numpy() for b in range(2)])
+    h1.remove(); h2.remove()
+    np.savez_compressed(os.path.join(out_dir, "tiny_sam_plain.npz"), mask_logits=masks.astype(np.float32),
+                        tap_hs=taps["hs"].astype(np.float32), tap_low_res_masks=taps["low_res_masks"].astype(np.float32))
+    print("sam_plain: masks", masks.shape, "std %.3f min %.3f max %.3f" % (masks.std(), masks.min(), masks.max()))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--demo-digest", action="store_true")
+    ap.add_argument("--only-sam-plain", action="store_true")
     ap.add_argument("--skip-tiny", action="store_true")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     mods = install_reference()
+    if args.only_sam_plain:
+        sam_plain(args.out, mods)
+        sys.exit(0)
     tokens(args.out, mods)
     if not args.skip_tiny:
         tiny(args.out, mods)
+    sam_plain(args.out, mods)
     if args.demo_digest:
         demo_digest(args.out, mods)
