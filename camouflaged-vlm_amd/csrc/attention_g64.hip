@@ -255,7 +255,15 @@ int launch_g64(const cvlm_attn_args& g, hipStream_t s) {
 }  // namespace
 
 // called from cvlm_attention() for mode 1, grid 64, head_dim 80
+int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s);   // attention_g64pp.hip
+
 int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s) {
+    static int pp = -1;
+    if (pp < 0) { const char* e = getenv("CVLM_ATTN_G64PP"); pp = e ? atoi(e) : 1; }
+    if (g.split_qk == 3 && g.split_pv == 3 && pp) {
+        const int rc = cvlm_attention_global64_pp(g, s);
+        if (rc != CVLM_E_UNSUPPORTED) return rc;                     // no workspace: the single-group kernel below needs none
+    }
     if (g.split_qk == 3 && g.split_pv == 3) return launch_g64<3, 3>(g, s);
     if (g.split_qk == 3 && g.split_pv == 1) return launch_g64<3, 1>(g, s);
     if (g.split_qk == 1 && g.split_pv == 1) return launch_g64<1, 1>(g, s);

@@ -1,0 +1,461 @@
+// ViT-H *global* attention on the 64x64 token map, ping-pong schedule (exact mode: hi/lo operands on both GEMMs).
+// Same mathematics and operand layouts as attention_g64.hip (query on the lane for S^T = K.Q^T and O^T = V^T.P^T,
+// rel-pos bias = Th[q][kh] from LDS + Tw[q][kw] from 32 registers); what changes is WHO runs WHEN:
+//
+//   * one workgroup of 8 waves per 256 queries; waves w and w + 4 share a SIMD.  A key tile costs a wave two phases,
+//         X(t): softmax of S(t)                      -- VALU / transcendental only
+//         Y(t): O += V(t)^T.P(t), then S(t+1) = K(t+1).Q^T   -- MFMA + LDS reads only
+//     and waves 4..7 run one phase behind waves 0..3, a raw s_barrier closing every phase.  In every phase one
+//     wave of each SIMD pair is in X and its partner in Y, so the matrix pipe and the VALU are both busy all the
+//     time (with two independent 4-wave workgroups per CU the same phases collided at random: MFMA busy 44 %,
+//     VALU 46 %, sum ~ 90 %).
+//   * V is consumed TRANSPOSED (rows = head dims, 32 keys per row): a small kernel writes V^T once per launch, so the
+//     A fragments of O^T = V^T.P^T are plain ds_read_b128 (256 B/clk).  Read from the [key][dim] image with
+//     ds_read_b64_tr_b16 (64 B/clk, 24 per tile and wave) the four waves of a phase saturated the LDS array: Y took
+//     1.13 us against 0.79 us for its 33 MFMAs alone (probe builds, tools/trace_attn_g64.py).
+//   * K and V tiles (32 keys) arrive by LDS-DMA into two three-slot rings, K running one tile ahead of V; they are
+//     issued three (K) / two (V) tiles before their first use and retired with counted vmcnt, never drained.
+#include <mutex>
+#include "common.h"
+#include "../../include/cvlm.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef CVLM_G64_PD
+#define CVLM_G64_PD 3
+#endif
+
+// phase-time probe (tools/trace_attn_g64.py): per wave 8 x u64 {prologue, sum X, sum X-side wait+barrier, sum Y, sum Y-side wait+barrier, total}
+__device__ unsigned long long* g_g64_trace = nullptr;
+
+__device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
+    typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
+    fp16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS fp16x4*)p);
+    return __builtin_bit_cast(half4, r);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void phase_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
+                                                            const half_t* __restrict__ vt_lo) {
+    constexpr int HD = 80, KS = 5, ND = 3, KP = 88, KT = 32, L = 64, LTP = 65, S = L * L, NTILE = S / KT;
+    constexpr int VROWS = 96, VROW_B = KT * 2;                       // V^T image: 96 rows (80 dims + 16 filler) x 32 keys
+    constexpr int KPL_B = KT * KP * 2, VPL_B = VROWS * VROW_B;       // plane bytes: 5632 / 6144
+    constexpr int KSLOT_B = 2 * KPL_B, VSLOT_B = 2 * VPL_B, NSLOT = 3;
+    constexpr int KPL = KPL_B / 2;                                   // K plane pitch in halves
+    constexpr int DPW = 3;                                           // DMA instructions per wave per tile
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Kring = smem;
+    unsigned char* Vring = smem + NSLOT * KSLOT_B;
+    float* T = (float*)(Vring + NSLOT * VSLOT_B);                    // [256][LTP]  (Tw first, then Th)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* const trace = g_g64_trace;
+    const unsigned long long tr_start = trace ? wall_clock64() : 0;
+    unsigned long long tr_x = 0, tr_xb = 0, tr_y = 0, tr_yb = 0, tr_pro = 0;
+    const bool grpB = wave >= 4;
+    const int qc = lane & 31, half = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int D = g.heads * HD;
+    const half_t* qkv_hi = (const half_t*)g.qkv_hi;
+    const half_t* qkv_lo = (const half_t*)g.qkv_lo;
+    const QkvStrides QS = qkv_strides(g.qkv_layout, S, g.B, g.heads, HD);
+
+    // ---- DMA plan: waves 0..3 carry K (12 one-KiB instructions per tile: 2 planes x 6), waves 4..7 carry V.
+    // Lane chunk c of a plane image: K rows are 11 chunks (10 data + 1 pad), V rows 12 (10 + 2); pad chunks re-read
+    // chunk 0; the K image ends at chunk 352, so the upper half of its sixth instruction is masked off.
+    const half_t* dsrc[DPW];
+    int ddst[DPW];
+    bool dok[DPW];
+    int64_t tile_stride;                                             // elements between consecutive key tiles
+    if (!grpB) {                                                     // K: [key][dim] rows of 11 chunks (10 data + 1 pad)
+        tile_stride = (int64_t)KT * QS.st;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int i = wave * DPW + j;                            // 0..11
+            const int pl = i / 6, sub = i - pl * 6;
+            const int c = sub * 64 + lane;
+            int row = c / 11, ch = c - row * 11;
+            dok[j] = row < KT;                                       // the K image ends at chunk 352
+            if (row >= KT) row = KT - 1;
+            if (ch >= 10) ch = 0;
+            dsrc[j] = (pl ? qkv_lo : qkv_hi) + qkv_offset(QS, b, row, 1, head) + ch * 8;
+            ddst[j] = pl * KPL_B + sub * 1024;
+        }
+    } else {                                                         // V^T: [dim][key] rows of 4 chunks, rows 80..95 repeat row 79
+        tile_stride = KT;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int i = (wave - 4) * DPW + j;
+            const int pl = i / 6, sub = i - pl * 6;
+            const int row = sub * 16 + (lane >> 2), pos = lane & 3;
+            const int chunk = pos ^ ((row >> 2) & 3);                // LDS position pos holds key chunk pos ^ f(row): conflict-free b128 reads
+            const int drow = row < HD ? row : HD - 1;
+            dok[j] = true;
+            dsrc[j] = (pl ? vt_lo : vt_hi) + (((int64_t)b * g.heads + head) * HD + drow) * S + chunk * 8;
+            ddst[j] = pl * VPL_B + sub * 1024;
+        }
+    }
+    // dsrc[] always points at the next tile this wave has to fetch (running pointers: a `t * stride` product
+    // ended up spilled and reloaded behind a vmcnt(0) in front of every DMA instruction)
+    auto issue_next = [&](int slot) {                                // this wave's share of the next K or V tile
+        unsigned char* base = (grpB ? Vring + slot * VSLOT_B : Kring + slot * KSLOT_B);
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            if (dok[j]) glds16(dsrc[j], base + ddst[j]);
+            dsrc[j] += tile_stride;
+        }
+    };
+    // prologue DMA: K(0..2) by waves 0..3, V(0..1) by waves 4..7 (they land under the table build below)
+    issue_next(0);
+    issue_next(1);
+    if (!grpB) issue_next(2);
+
+    // ---- queries, rel-pos tables
+    const int qslot = blockIdx.x * 256 + wave * 32 + qc;
+    half8 qh[KS], ql[KS];
+    {
+        const int64_t qo = qkv_offset(QS, b, qslot, 0, head);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qh[ks] = *(const half8*)(qkv_hi + qo + 16 * ks + 8 * half);
+            ql[ks] = *(const half8*)(qkv_lo + qo + 16 * ks + 8 * half);
+        }
+    }
+    const int qhh = qslot >> 6, qww = qslot & 63;
+    float* Tq = T + (wave * 32 + qc) * LTP;
+    auto build_table = [&](const half_t* Rhi, const half_t* Rlo, int cq) {   // T[q][k] = (Q . R^T)[q][cq - k + 63]
+#pragma unroll 1
+        for (int st = 0; st < 4; ++st) {
+            floatx16 u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = 0.f;
+            int rr = st * 32 + qc;
+            rr = rr < 127 ? rr : 126;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 ah = *(const half8*)(Rhi + rr * HD + 16 * ks + 8 * half);
+                const half8 al = *(const half8*)(Rlo + rr * HD + 16 * ks + 8 * half);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], u, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int kidx = cq + 63 - j;
+                if (j < 127 && kidx >= 0 && kidx < L) Tq[kidx] = u[r];
+            }
+        }
+    };
+    f32x2 twr[2][8];                                                 // Tw[q][32*pz + (r&3) + 8*(r>>2) + 4*half], r = 2i, 2i+1
+    build_table((const half_t*)g.relw_hi, (const half_t*)g.relw_lo, qww);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r0 = 2 * i, r1 = 2 * i + 1;
+            twr[pz][i] = f32x2{Tq[32 * pz + (r0 & 3) + 8 * (r0 >> 2) + 4 * half], Tq[32 * pz + (r1 & 3) + 8 * (r1 >> 2) + 4 * half]};
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // each lane re-reads only the row it wrote
+    build_table((const half_t*)g.relh_hi, (const half_t*)g.relh_lo, qhh);
+    // the rel-pos tables use q as is (image_encoder.py:497-500); the scores use q * scale (:496): fold it in now
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            half_t hh, ll;
+            split_h2(((float)qh[ks][j] + (float)ql[ks][j]) * g.scale, hh, ll);
+            qh[ks][j] = hh; ql[ks][j] = ll;
+        }
+
+    // ---- state
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx16 o[ND], s;
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    half8 ph[2] = {}, pl[2] = {};
+    // byte offset of this lane's key chunk (keys 16 k2 + 8 half ..) inside its V^T row; rows 32 n + qc share (row >> 2) & 3
+    const int v_pos[2] = {((0 + half) ^ ((qc >> 2) & 3)) * 16, ((2 + half) ^ ((qc >> 2) & 3)) * 16};
+    const int k_lane_off = qc * KP + 8 * half;
+
+    auto QK = [&](int slot) {                                        // S^T = K_tile . Q^T  (3 MFMAs per k-step)
+        const half_t* kr = (const half_t*)(Kring + slot * KSLOT_B) + k_lane_off;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const half8 kh = *(const half8*)(kr + 16 * ks);
+            const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+        }
+    };
+    // Y(t): O^T += V(t)^T . P^T (six fragment groups), then S^T = K(t+1) . Q^T (five k-steps) as ONE stream of
+    // eleven stages; the LDS fragments of stage i + 2 are requested before the three MFMAs of stage i are issued.
+    // The partner wave on this SIMD is in its VALU phase, so nothing else would cover this wave's LDS latency.
+    auto Y = [&](int vslot, int kslot) {
+        const unsigned char* vbase = Vring + vslot * VSLOT_B + qc * VROW_B;      // row = 32 n + qc of the V^T image
+        const half_t* kr = (const half_t*)(Kring + kslot * KSLOT_B) + k_lane_off;
+        constexpr int PD = CVLM_G64_PD, RS = PD + 1;                 // fragments requested PD stages ahead, ring of PD + 1
+        half8 fa[RS], fb[RS];                                        // (hi, lo) fragment pair per stage
+        auto load = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+#ifdef CVLM_G64_NOLDS                                                // probe: 1 = no fragment reads, 2 = no V reads, 3 = no K reads
+            if constexpr (CVLM_G64_NOLDS == 1 || (CVLM_G64_NOLDS == 2 && I < 6) || (CVLM_G64_NOLDS == 3 && I >= 6)) {
+                fa[I % RS] = qh[I % 5]; fb[I % RS] = ql[I % 5];
+                asm volatile("" : "+v"(fa[I % RS]), "+v"(fb[I % RS]));
+                return;
+            }
+#endif
+            if constexpr (I < 6) {
+                constexpr int k2 = I / 3, n = I % 3;
+                const unsigned char* vr = vbase + (32 * n) * VROW_B + v_pos[k2];
+                fa[I % RS] = *(const half8*)vr;
+                fb[I % RS] = *(const half8*)(vr + VPL_B);
+            } else {
+                constexpr int ks = I - 6;
+                fa[I % RS] = *(const half8*)(kr + 16 * ks);
+                fb[I % RS] = *(const half8*)(kr + KPL + 16 * ks);
+            }
+        };
+        auto compute = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            const half8 a = fa[I % RS], bq = fb[I % RS];
+            if constexpr (I < 6) {
+                constexpr int k2 = I / 3, n = I % 3;
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ph[k2], o[n], 0, 0, 0);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, ph[k2], o[n], 0, 0, 0);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pl[k2], o[n], 0, 0, 0);
+            } else {
+                constexpr int ks = I - 6;
+                if constexpr (ks == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s, 0, 0, 0);
+            }
+        };
+        load(std::integral_constant<int, 0>{});
+        if constexpr (PD >= 2) load(std::integral_constant<int, 1>{});
+        if constexpr (PD >= 3) load(std::integral_constant<int, 2>{});
+        auto stage = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if constexpr (I + PD <= 10) load(std::integral_constant<int, I + PD>{});
+            compute(ic);
+            // issue order inside the stage: MFMA, two LDS reads, MFMA, two LDS reads, MFMA -- a burst of four reads
+            // in front of the MFMAs stalled their issue by ~40 cycles per stage (LDS queue), two per gap are free
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{});
+        stage(std::integral_constant<int, 2>{}); stage(std::integral_constant<int, 3>{});
+        stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+        stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{});
+        stage(std::integral_constant<int, 8>{}); stage(std::integral_constant<int, 9>{});
+        stage(std::integral_constant<int, 10>{});
+    };
+    // X(t): online softmax of S -> P (hi, lo fragments).  Q carries `scale`, so S is already in score units; the VALU
+    // issue port is what bounds this phase (the partner's MFMAs take 8 of every 32 issue cycles), hence: packed fp32
+    // adds / fmas, the key-row bias th folded into the exponent's constant, single-instruction exp2, and the hi/lo
+    // split as cvt_pkrtz + (e - hi) + cvt_pkrtz (hi truncated instead of rounded: lo absorbs the difference exactly).
+    auto X = [&](const f32x2 (&tw)[8], float th) {
+#ifdef CVLM_G64_NOX
+        asm volatile("" : "+v"(ph[0]), "+v"(ph[1]), "+v"(pl[0]), "+v"(pl[1]));   // probe: no VALU phase
+        return;
+#endif
+        f32x2 z[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = f32x2{s[2 * i], s[2 * i + 1]} + tw[i];
+        float mx = fmaxf(z[0].x, z[0].y);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) mx = fmaxf(fmaxf(mx, z[i].x), z[i].y);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) + th;
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const f32x2 c2 = f32x2{(th - m_new) * LOG2E, (th - m_new) * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 a = z[i] * l2 + c2;
+            z[i] = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+            acc += z[i];
+        }
+        l_run = l_run * alpha + (acc.x + acc.y);
+        if (!__all(m_new == m_run)) {
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+        }
+        m_run = m_new;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x2 e = z[4 * k2 + p];
+                const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x, e.y));
+                const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x - (float)h[0], e.y - (float)h[1]));
+                ph[k2][2 * p] = h[0]; ph[k2][2 * p + 1] = h[1];
+                pl[k2][2 * p] = l[0]; pl[k2][2 * p + 1] = l[1];
+            }
+    };
+
+    // ---- every wave runs the same sequence  QK(0) | X(0) Y(0) | X(1) Y(1) | ...  with Y(t) = PV(t), QK(t+1);
+    // group B enters it one barrier later and leaves it one barrier earlier, so that in every phase one wave of a
+    // SIMD pair is in X and the other in Y.  Global phase p: A runs X(t) at p = 2t, Y(t) at 2t + 1; B one later.
+    //   reads:  K(t+1), V(t) by A in phase 2t + 1, by B in phase 2t + 2
+    //   DMA:    at the start of its Y(t) a K-carrier (group A) fetches K(t+3) into K(t)'s slot, a V-carrier (group B)
+    //           V(t+2) into V(t-1)'s slot -- both last read one phase earlier -- and the batch is retired two of the
+    //           carrier's own phases later with vmcnt(DPW) (one younger batch may stay in flight), in front of the
+    //           barrier that closes an even global phase; first use is A's Y(t+2) right behind that barrier.
+    wait_vm<0>();
+    phase_barrier();
+    if (grpB) phase_barrier();                                       // B starts one phase late
+    QK(0);
+    phase_barrier();
+    if (trace) tr_pro = wall_clock64() - tr_start;
+    int s0 = 0, s1 = 1, s2 = 2;                                      // t % 3, (t + 1) % 3, (t + 2) % 3
+    auto tile_phases = [&](auto pz_c, int t) {
+        constexpr int PZ = decltype(pz_c)::value;
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (trace) c0 = wall_clock64();
+        X(twr[PZ], Tq[t >> 1]);
+        if (trace) { asm volatile("" ::"v"(ph[0]), "v"(pl[1])); c1 = wall_clock64(); }
+        if (!grpB) { if (t + 5 >= NTILE) wait_vm<0>(); else wait_vm<DPW>(); }
+        phase_barrier();
+        if (trace) c2 = wall_clock64();
+        if (!grpB) { if (t + 3 < NTILE) issue_next(s0); }
+        else       { if (t + 2 < NTILE) issue_next(s2); }
+        Y(s0, s1);                                                  // the last S (tile NTILE) is computed and dropped
+        if (trace) { asm volatile("" ::"v"(s[0]), "v"(o[2][0])); c3 = wall_clock64(); }
+        if (grpB) { if (t + 5 >= NTILE) wait_vm<0>(); else wait_vm<DPW>(); }
+        phase_barrier();
+        if (trace) { const unsigned long long c4 = wall_clock64(); tr_x += c1 - c0; tr_xb += c2 - c1; tr_y += c3 - c2; tr_yb += c4 - c3; }
+        const int n0 = s1; s1 = s2; s2 = s0; s0 = n0;
+    };
+#pragma unroll 1
+    for (int t = 0; t < NTILE; t += 2) {
+        tile_phases(std::integral_constant<int, 0>{}, t);
+        tile_phases(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (!grpB) phase_barrier();                                      // match B's extra leading barrier
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int64_t orow = ((int64_t)b * S + qslot) * D + head * HD;
+    half_t* oh = (half_t*)g.out_hi + orow;
+    half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d = 32 * n + 8 * rg + 4 * half;
+            if (d < HD) {
+                half_t h[4], l4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_h2(o[n][4 * rg + j] * inv, h[j], l4[j]);
+                *(half4*)(oh + d) = half4{h[0], h[1], h[2], h[3]};
+                if (ol) *(half4*)(ol + d) = half4{l4[0], l4[1], l4[2], l4[3]};
+            }
+        }
+    if (trace && lane == 0) {
+        unsigned long long* o8 = trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        o8[0] = tr_pro; o8[1] = tr_x; o8[2] = tr_xb; o8[3] = tr_y; o8[4] = tr_yb; o8[5] = wall_clock64() - tr_start;
+    }
+}
+
+// V [key][dim] (as the qkv GEMM leaves it) -> V^T [b][head][dim][key'], both planes; 64 keys x 80 dims per workgroup
+__global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g, half_t* __restrict__ vt_hi,
+                                                          half_t* __restrict__ vt_lo) {
+    constexpr int HD = 80, S = 4096, TP = 88;                        // LDS row pitch in halves
+    __shared__ __attribute__((aligned(16))) half_t tile[2][64 * TP];
+    const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z, s0 = blockIdx.x * 64;
+    const QkvStrides QS = qkv_strides(g.qkv_layout, S, g.B, g.heads, HD);
+    const half_t* src[2] = {(const half_t*)g.qkv_hi, (const half_t*)g.qkv_lo};
+    for (int u = tid; u < 2 * 64 * 10; u += 256) {
+        const int pl = u / 640, r = (u % 640) / 10, ch = u % 10;
+        *(half8*)(&tile[pl][r * TP + ch * 8]) = *(const half8*)(src[pl] + qkv_offset(QS, b, s0 + r, 2, head) + ch * 8);
+    }
+    __syncthreads();
+    half_t* dst[2] = {vt_hi, vt_lo};
+    for (int u = tid; u < 2 * HD * 8; u += 256) {
+        const int pl = u / 640, d = (u % 640) / 8, c8 = u % 8;
+        // keys are stored in the order the P fragments hold them: element j of k-half h of a 16-key step is key
+        // (j & 3) + 8 (j >> 2) + 4 h (the row map of the 32x32 accumulator, which becomes the B operand unchanged)
+        const int g16 = c8 >> 1, h = c8 & 1;
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[pl][(16 * g16 + (j & 3) + 8 * (j >> 2) + 4 * h) * TP + d];
+        *(half8*)(dst[pl] + (((int64_t)b * g.heads + head) * HD + d) * S + s0 + c8 * 8) = v;
+    }
+}
+
+}  // namespace
+
+// ---- V^T workspace: one per stream, grown on demand (launches on one stream are ordered)
+struct VtWs { hipStream_t stream; half_t* buf; size_t halves; };
+static VtWs g_vt[8];
+static int g_vt_n = 0;
+static std::mutex g_vt_mu;
+static half_t* vt_workspace(hipStream_t st, size_t halves) {
+    std::lock_guard<std::mutex> lk(g_vt_mu);
+    VtWs* w = nullptr;
+    for (int i = 0; i < g_vt_n; ++i)
+        if (g_vt[i].stream == st) w = &g_vt[i];
+    if (!w) {
+        if (g_vt_n == 8) return nullptr;
+        w = &g_vt[g_vt_n++];
+        *w = VtWs{st, nullptr, 0};
+    }
+    if (w->halves < halves) {
+        if (w->buf) { (void)hipStreamSynchronize(st); (void)hipFree(w->buf); }
+        w->buf = nullptr; w->halves = 0;
+        if (hipMalloc((void**)&w->buf, halves * sizeof(half_t)) != hipSuccess) return nullptr;
+        w->halves = halves;
+    }
+    return w->buf;
+}
+
+// Probe hook (not part of include/cvlm.h).
+extern "C" int cvlm_debug_set_attn_g64_trace(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_g64_trace), &buf, sizeof(buf));
+}
+
+// exact-mode (split 3/3) fast path of cvlm_attention_global64()
+int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s) {
+    constexpr int smem = 3 * (2 * 5632) + 3 * (2 * 6144) + 256 * 65 * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr = true;
+    }
+    const size_t plane = (size_t)g.B * g.heads * 80 * 4096;
+    half_t* vt = vt_workspace(s, 2 * plane);
+    if (!vt) return CVLM_E_UNSUPPORTED;                              // caller falls back to the single-wave-group kernel
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(4096 / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
+    CVLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_g64pp_kernel, dim3(4096 / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
+                       (const half_t*)(vt + plane));
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}

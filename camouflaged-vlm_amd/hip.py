@@ -64,7 +64,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HIP kernels are the only compute path of this package. "
             "Build them with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(os.environ.get("CVLM_PROBE_LIB") or LIB_PATH)      # CVLM_PROBE_LIB: probe builds of the same ABI (tools/)
     lib.cvlm_abi_version.restype = C.c_int
     lib.cvlm_target_arch.restype = C.c_char_p
     for name in EXPORTS[2:]:
