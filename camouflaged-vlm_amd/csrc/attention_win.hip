@@ -20,6 +20,7 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
     typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
@@ -188,14 +189,24 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     __syncthreads();
     {
         // augmented B fragments: k-step 5 covers aug dims 0..15, k-step 6 dims 16..31; lane holds dims 8*half .. +8
-        const float inv_scale = 1.0f / g.scale;
+        // the scores use q * scale (image_encoder.py:496), the rel-pos tables q itself (:497-500): fold the scale
+        // into the query fragments now that U is done; the augmented columns then carry T unscaled
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                half_t hh, ll;
+                split_h2(((float)qh[ks][j] + (SQK == 3 ? (float)ql[ks][j] : 0.f)) * g.scale, hh, ll);
+                qh[ks][j] = hh;
+                if (SQK == 3) ql[ks][j] = ll;
+            }
         const float* Tq = Taug + (wave * 32 + qc) * 33;
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 half_t h, l;
-                split_h2(Tq[16 * a + 8 * half + j] * inv_scale, h, l);
+                split_h2(Tq[16 * a + 8 * half + j], h, l);
                 qh[KS + a][j] = h;
                 ql[KS + a][j] = (SQK == 3) ? l : (half_t)0.f;
             }
@@ -209,7 +220,6 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     for (int n = 0; n < ND; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-    const float scale = g.scale;
     if (trace) tr1 = wall_clock64();
     const int tg = lane >> 4, ti = lane & 15;
     const int v_lane_off = (4 * (tg >> 1) + (ti >> 2)) * VP + 16 * (tg & 1) + 4 * (ti & 3);
@@ -244,27 +254,28 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, qh[KS + a], s, 0, 0, 0);
                 if (SQK == 3) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, ql[KS + a], s, 0, 0, 0);
             }
-            const int b0 = t * KT + sub * 32 + 4 * half;
-            float mx = -INFINITY;
+            // online softmax on packed fp32 pairs; only the last tile holds slots beyond the 196 keys
+            if (t == NKT - 1) {
+                const int b0 = t * KT + sub * 32 + 4 * half;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int slot = b0 + (r & 3) + 8 * (r >> 2);
-                const float v = (slot < S_SEQ) ? s[r] * scale : -INFINITY;
-                s[r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 16; ++r)
+                    if (b0 + (r & 3) + 8 * (r >> 2) >= S_SEQ) s[r] = -INFINITY;
             }
+            float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f((m_run - m_new) * LOG2E);
-            const float mneg = m_new * LOG2E;
-            float ps = 0.f;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            const f32x2 c2 = f32x2{-m_new * LOG2E, -m_new * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
+            f32x2 z[8], acc = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[r] * LOG2E - mneg);
-                s[r] = e;
-                ps += e;
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 a = f32x2{s[2 * i], s[2 * i + 1]} * l2 + c2;
+                z[i] = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                acc += z[i];
             }
-            l_run = l_run * alpha + ps;
+            l_run = l_run * alpha + (acc.x + acc.y);
             if (!__all(m_new == m_run)) {
 #pragma unroll
                 for (int n = 0; n < ND; ++n)
@@ -276,11 +287,14 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
             for (int k2 = 0; k2 < 2; ++k2) {
                 half8 ph, pl;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    half_t eh, el;
-                    split_h2(s[8 * k2 + j], eh, el);
-                    ph[j] = eh;
-                    if (SPV == 3) pl[j] = el;
+                for (int p2 = 0; p2 < 4; ++p2) {                      // hi truncated (cvt_pkrtz), lo = e - hi: exact remainder
+                    const f32x2 e = z[4 * k2 + p2];
+                    const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x, e.y));
+                    ph[2 * p2] = h[0]; ph[2 * p2 + 1] = h[1];
+                    if (SPV == 3) {
+                        const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x - (float)h[0], e.y - (float)h[1]));
+                        pl[2 * p2] = l[0]; pl[2 * p2 + 1] = l[1];
+                    }
                 }
                 const half_t* vb = Vs + (sub * 32 + 16 * k2) * VP + v_lane_off;
 #pragma unroll
