@@ -29,6 +29,7 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct AttnParams {
     cvlm_attn_args a;
@@ -265,16 +266,16 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                 }
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run, mx);
-                const float alpha = exp2f((m_run - m_new) * LOG2E);
-                const float mneg = m_new * LOG2E;
-                float ps = 0.f;
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+                const f32x2 c2 = f32x2{-m_new * LOG2E, -m_new * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
+                f32x2 z[8], acc = f32x2{0.f, 0.f};                   // packed fp32: half the VALU instructions
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = exp2f(s[r] * LOG2E - mneg);
-                    s[r] = e;
-                    ps += e;
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2 a = f32x2{s[2 * i], s[2 * i + 1]} * l2 + c2;
+                    z[i] = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                    acc += z[i];
                 }
-                l_run = l_run * alpha + ps;
+                l_run = l_run * alpha + (acc.x + acc.y);
                 if (!__all(m_new == m_run)) {
 #pragma unroll
                     for (int n = 0; n < ND; ++n)
@@ -287,11 +288,14 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                 for (int k2 = 0; k2 < 2; ++k2) {
                     half8 ph, pl;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        half_t eh, el;
-                        split_h2(s[8 * k2 + j], eh, el);
-                        ph[j] = eh;
-                        if (SPV == 3) pl[j] = el;
+                    for (int p2 = 0; p2 < 4; ++p2) {                  // hi truncated (cvt_pkrtz), lo = e - hi: exact remainder
+                        const f32x2 e = z[4 * k2 + p2];
+                        const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x, e.y));
+                        ph[2 * p2] = h[0]; ph[2 * p2 + 1] = h[1];
+                        if (SPV == 3) {
+                            const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x - (float)h[0], e.y - (float)h[1]));
+                            pl[2 * p2] = l[0]; pl[2 * p2 + 1] = l[1];
+                        }
                     }
                     const half_t* vb = Vs + (sub * 32 + 16 * k2) * KP + v_lane_off;
 #pragma unroll
