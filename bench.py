@@ -204,6 +204,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                                   # rank 0 ran the instrumented roofline repeat meanwhile
         dist.destroy_process_group()
 
 
