@@ -42,45 +42,83 @@ __global__ __launch_bounds__(256) void mask_to_u8_kernel(const float* __restrict
     }
 }
 
-// gt > 128 -> (count, sum x, sum y) per image; stats is u64 [N][3], zeroed by the launcher
+// gt > 128 -> per-workgroup (count, sum x, sum y) partials, image n's at partial[n * 1024 + 3 * block .. ].
+// 16 pixels per thread and iteration (one 16-byte load); x / y of a 16-pixel run are derived once per run.
 __global__ __launch_bounds__(256) void gt_centroid_kernel(const uint8_t* __restrict__ gt, int h, int w,
-                                                          unsigned long long* __restrict__ stats) {
+                                                          unsigned long long* __restrict__ partial) {
     const int n = blockIdx.y;
     const uint8_t* g = gt + (int64_t)n * h * w;
     const int64_t total = (int64_t)h * w;
+    const bool vec = ((total & 15) == 0) && ((((uintptr_t)g) & 15) == 0);
     unsigned long long cnt = 0, sx = 0, sy = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        if (g[i] > 128) { cnt += 1; sx += (unsigned long long)(i % w); sy += (unsigned long long)(i / w); }
+    const int64_t nrun = (total + 15) >> 4;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrun; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i0 = r << 4;
+        uint8_t px[16];
+        if (vec) {
+            *(uint4*)px = *(const uint4*)(g + i0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) px[j] = i0 + j < total ? g[i0 + j] : 0;
+        }
+        int y = (int)(i0 / w), x = (int)(i0 - (int64_t)y * w);
+        unsigned c = 0, ax = 0, ay = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (px[j] > 128) { c += 1; ax += (unsigned)x; ay += (unsigned)y; }
+            if (++x == w) { x = 0; ++y; }
+        }
+        cnt += c; sx += ax; sy += ay;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         cnt += __shfl_xor(cnt, o, 64); sx += __shfl_xor(sx, o, 64); sy += __shfl_xor(sy, o, 64);
     }
-    if ((threadIdx.x & 63) == 0 && cnt) {
-        atomicAdd(&stats[3 * n + 0], cnt); atomicAdd(&stats[3 * n + 1], sx); atomicAdd(&stats[3 * n + 2], sy);
-    }
+    // one partial per workgroup, no atomics: 768 same-address device-scope atomics per image took 150 us
+    __shared__ unsigned long long part[4][3];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = cnt; part[threadIdx.x >> 6][1] = sx; part[threadIdx.x >> 6][2] = sy; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        partial[(int64_t)n * 1024 + blockIdx.x * 3 + threadIdx.x] =          // image n's triples live in image n's 8 KB
+            part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
-// one wave adds its 64 (bin, valid) pairs to an LDS histogram with one atomic per distinct bin
-__device__ __forceinline__ void wave_hist_add(unsigned* hist, int bin, bool valid) {
-    unsigned long long todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b = __shfl(bin, leader, 64);
-        const unsigned long long same = __ballot(valid && bin == b) & todo;
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (unsigned)__popcll(same));
-        todo &= ~same;
+// sums the per-workgroup partials of one image into stats[n] and clears that image's histogram (whose memory the
+// partials were parked in)
+__global__ __launch_bounds__(256) void centroid_finalize_kernel(unsigned long long* __restrict__ partial, int nparts,
+                                                                unsigned long long* __restrict__ stats,
+                                                                unsigned* __restrict__ hist) {
+    const int n = blockIdx.x;
+    __shared__ unsigned long long red[256][3];
+    unsigned long long a[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < nparts; i += 256)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a[k] += partial[(int64_t)n * 1024 + i * 3 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) red[threadIdx.x][k] = a[k];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[threadIdx.x][k] += red[threadIdx.x + o][k];
+        __syncthreads();
     }
+    if (threadIdx.x < 3) stats[3 * n + threadIdx.x] = red[0][threadIdx.x];
+    __syncthreads();                                                  // every partial has been read
+    for (int i = threadIdx.x; i < 2048; i += 256) hist[(int64_t)n * 2048 + i] = 0;
 }
 
 // hist u32 [N][4 quadrants][2 gt][256 levels]; quadrant split at the S-measure centroid (x, y) = round(mean) + 1,
 // (round(w/2), round(h/2)) + 1 for an empty ground truth: LT = [0:y, 0:x], RT = [0:y, x:], LB = [y:, 0:x], RB.
+// One LDS histogram per wave (4 x 8 KB), 16 pixels per lane and iteration.  Camouflage masks are mostly flat: when
+// all 64 lanes of a wave hold the same bin for their j-th pixel, one lane adds 64; otherwise plain LDS atomics.
 __global__ __launch_bounds__(256) void joint_hist_kernel(const uint8_t* __restrict__ pre, const uint8_t* __restrict__ gt,
                                                          int h, int w, const unsigned long long* __restrict__ stats,
                                                          unsigned* __restrict__ hist) {
-    __shared__ unsigned lh[4 * 2 * 256];
-    const int n = blockIdx.y;
-    for (int i = threadIdx.x; i < 2048; i += 256) lh[i] = 0;
+    __shared__ unsigned lh[4][2048];
+    const int n = blockIdx.y, lane = threadIdx.x & 63;
+    unsigned* my = lh[threadIdx.x >> 6];
+    for (int i = threadIdx.x; i < 4 * 2048; i += 256) (&lh[0][0])[i] = 0;
     const unsigned long long cnt = stats[3 * n];
     int cx, cy;
     if (cnt == 0) {
@@ -92,23 +130,45 @@ __global__ __launch_bounds__(256) void joint_hist_kernel(const uint8_t* __restri
     const uint8_t* p = pre + (int64_t)n * h * w;
     const uint8_t* g = gt + (int64_t)n * h * w;
     const int64_t total = (int64_t)h * w;
+    const bool vec = ((total & 15) == 0) && ((((uintptr_t)p) & 15) == 0) && ((((uintptr_t)g) & 15) == 0);
+    const int64_t nrun = (total + 15) >> 4;
     const int64_t span = (int64_t)gridDim.x * blockDim.x;
-    const int64_t rounds = (total + span - 1) / span;          // every lane runs every round: ballots stay wave-uniform
-    for (int64_t r = 0; r < rounds; ++r) {
-        const int64_t i = r * span + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool valid = i < total;
-        int bin = 0;
-        if (valid) {
-            const int x = (int)(i % w), y = (int)(i / w);
-            const int q = (y >= cy ? 2 : 0) + (x >= cx ? 1 : 0);
-            bin = (q * 2 + (g[i] > 128 ? 1 : 0)) * 256 + (int)p[i];
+    const int64_t rounds = (nrun + span - 1) / span;                 // every lane runs every round: ballots stay wave-uniform
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t r = rd * span + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const int64_t i0 = r << 4;
+        uint8_t pp[16], gg[16];
+        if (vec && r < nrun) {
+            *(uint4*)pp = *(const uint4*)(p + i0);
+            *(uint4*)gg = *(const uint4*)(g + i0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = r < nrun && i0 + j < total;
+                pp[j] = ok ? p[i0 + j] : 0; gg[j] = ok ? g[i0 + j] : 0;
+            }
         }
-        wave_hist_add(lh, bin, valid);
+        int y = (int)(i0 / w), x = (int)(i0 - (int64_t)y * w);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool valid = r < nrun && i0 + j < total;
+            const int q = (y >= cy ? 2 : 0) + (x >= cx ? 1 : 0);
+            const int bin = (q * 2 + (gg[j] > 128 ? 1 : 0)) * 256 + (int)pp[j];
+            const int first = __shfl(bin, 0, 64);
+            if (__all(valid && bin == first)) {
+                if (lane == 0) atomicAdd(&my[first], 64u);
+            } else if (valid) {
+                atomicAdd(&my[bin], 1u);
+            }
+            if (++x == w) { x = 0; ++y; }
+        }
     }
     __syncthreads();
     unsigned* out = hist + (int64_t)n * 2048;
-    for (int i = threadIdx.x; i < 2048; i += 256)
-        if (lh[i]) atomicAdd(&out[i], lh[i]);
+    for (int i = threadIdx.x; i < 2048; i += 256) {
+        const unsigned v = lh[0][i] + lh[1][i] + lh[2][i] + lh[3][i];
+        if (v) atomicAdd(&out[i], v);
+    }
 }
 
 // scores f32 [B][C], labels i32 [B] -> pred i32 [B] (first maximum), counters u32 {top-1 hits, top-5 hits, rows}
@@ -154,12 +214,12 @@ int cvlm_mask_joint_hist(const uint8_t* pre, const uint8_t* gt, int32_t N, int32
                          void* stream) {
     if (!pre || !gt || !stats || !hist || N <= 0 || h <= 0 || w <= 0) return CVLM_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)N * 3 * sizeof(uint64_t), st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(hist, 0, (size_t)N * 2048 * sizeof(uint32_t), st);
-    if (e != hipSuccess) return (int)e;
-    const int gx = grid_for((int64_t)h * w, 256);
-    hipLaunchKernelGGL(gt_centroid_kernel, dim3(gx, N), dim3(256), 0, st, gt, h, w, (unsigned long long*)stats);
+    // partials are parked in the histogram buffer itself: image n's 8 KB (1024 u64) hold its <= 256 triples
+    const int gx = grid_for(((int64_t)h * w + 15) / 16, 256);         // 16 pixels per thread and round; <= 256 partials
+    unsigned long long* partial = (unsigned long long*)hist;
+    hipLaunchKernelGGL(gt_centroid_kernel, dim3(gx, N), dim3(256), 0, st, gt, h, w, partial);
+    CVLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(centroid_finalize_kernel, dim3(N), dim3(256), 0, st, partial, gx, (unsigned long long*)stats, hist);
     CVLM_CHECK_LAUNCH();
     hipLaunchKernelGGL(joint_hist_kernel, dim3(gx, N), dim3(256), 0, st, pre, gt, h, w, (const unsigned long long*)stats, hist);
     CVLM_CHECK_LAUNCH();
