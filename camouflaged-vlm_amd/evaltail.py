@@ -5,6 +5,8 @@ numpy (test_ovcos_maskdecoder_edge.py:116-136, recorder/ovcos_metricer.py).  Eve
 weighted F-measure only depends on the uint8 mask through counts: per S-measure quadrant, per ground-truth class, per
 level.  `mask_counts` produces exactly those counters on the GPU (`csrc/evaltail.hip`); the functions below turn the
 8 KB of counters per image into MAE, adaptive / changeable F, E and IoU measures and the S-measure in float64.
+The weighted F-measure is spatial (distance transform, 7x7 Gaussian): `mask_wfm_sums` runs it on the GPU in float64
+and returns three sums per image.
 
 There is no CPU path: `mask_counts` and `DeviceClassification` raise if the HIP library is missing.
 """
@@ -20,7 +22,7 @@ from . import hip
 
 _EPS = np.spacing(1)
 CURVE_METRICS = ("fm", "em", "iou")
-SUPPORTED = ("sm", "mae", "fm", "em", "iou")
+SUPPORTED = ("sm", "wfm", "mae", "fm", "em", "iou")
 
 
 # ---- device side -----------------------------------------------------------------------------------------------------
@@ -41,6 +43,41 @@ def mask_counts(pre: torch.Tensor, gt: torch.Tensor):
     hist = torch.empty((n, 4, 2, 256), dtype=torch.int32, device=pre.device)
     hip.mask_joint_hist(pre.contiguous(), gt.contiguous(), stats, hist)
     return stats, hist
+
+
+_GAUSS: Dict[str, torch.Tensor] = {}
+
+
+def _gauss49(device) -> torch.Tensor:
+    """fspecial('gaussian', 7, 5) as pysodmetrics builds it: exp(-(x^2+y^2)/(2 sigma^2)), tiny entries zeroed, sum 1."""
+    key = str(device)
+    if key not in _GAUSS:
+        y, x = np.ogrid[-3:4, -3:4]
+        k = np.exp(-(x * x + y * y) / (2.0 * 5.0 * 5.0))
+        k[k < np.finfo(k.dtype).eps * k.max()] = 0
+        k /= k.sum()
+        _GAUSS[key] = torch.from_numpy(np.ascontiguousarray(k.reshape(-1))).to(device)
+    return _GAUSS[key]
+
+
+def mask_wfm_sums(pre: torch.Tensor, gt: torch.Tensor, hist: torch.Tensor) -> torch.Tensor:
+    """pre / gt uint8 (N,h,w), hist from `mask_counts` -> float64 (N,3) = (sum Ew over gt, sum Ew over ~gt, |gt|)."""
+    n, h, w = pre.shape
+    ws = torch.empty(hip.mask_wfm_workspace_bytes(n, h, w), dtype=torch.uint8, device=pre.device)
+    out = torch.empty((n, 3), dtype=torch.float64, device=pre.device)
+    hip.mask_wfm(pre.contiguous(), gt.contiguous(), hist, _gauss49(pre.device), ws, out)
+    return out
+
+
+def wfm_from_sums(sums: np.ndarray, beta: float = 1.0) -> float:
+    """WeightedFmeasure.cal_wfm's last lines (0 for an empty ground truth, ovcos_metricer.py:56-59)."""
+    s_fg, s_bg, n1 = (float(v) for v in sums)
+    if n1 == 0:
+        return 0.0
+    tpw, fpw = n1 - s_fg, s_bg
+    r = 1 - s_fg / n1
+    p = tpw / (tpw + fpw + _EPS)
+    return (1 + beta) * r * p / (r + beta * p + _EPS)
 
 
 # ---- counters -> metrics (host, float64, 2048 numbers per image) ------------------------------------------------------
@@ -127,7 +164,8 @@ def _sm(hist: np.ndarray, norm: np.ndarray, stats: np.ndarray, h: int, w: int, a
 
 
 def metrics_from_counts(stats: np.ndarray, hist: np.ndarray, h: int, w: int, same_class: bool = True,
-                        metric_names: Sequence[str] = SUPPORTED) -> Dict[str, object]:
+                        metric_names: Sequence[str] = ("sm", "mae", "fm", "em", "iou"),
+                        wfm_sums: Optional[np.ndarray] = None) -> Dict[str, object]:
     """One image: stats (3,), hist (4,2,256) -> the per-image values OVCOSMetricer.step records
     (recorder/ovcos_metricer.py:13-141), zeroed (MAE: 1) when the predicted class is wrong."""
     hist = np.asarray(hist).astype(np.int64).reshape(4, 2, 256)
@@ -142,6 +180,10 @@ def metrics_from_counts(stats: np.ndarray, hist: np.ndarray, h: int, w: int, sam
     out: Dict[str, object] = {}
     if "sm" in metric_names:
         out["sm"] = float(_sm(hist, norm, np.asarray(stats), h, w))
+    if "wfm" in metric_names:
+        if wfm_sums is None:
+            raise ValueError("'wfm' needs the sums of mask_wfm_sums")
+        out["wfm"] = float(wfm_from_sums(wfm_sums))
     if "mae" in metric_names:
         out["mae"] = float(((total[1] * np.abs(norm - 1)).sum() + (total[0] * np.abs(norm)).sum()) / size)
     tp_a, fp_a = int(total[1][binary].sum()), int(total[0][binary].sum())
@@ -180,12 +222,9 @@ class DeviceMetricer:
 
     suppoted_metrics = sorted(SUPPORTED)
 
-    def __init__(self, class_names: Sequence[str], metric_names: Sequence[str] = ("sm", "mae", "fm", "em", "iou")):
+    def __init__(self, class_names: Sequence[str], metric_names: Sequence[str] = ("sm", "wfm", "mae", "fm", "em", "iou")):
         self.class_names = list(class_names)
         metric_names = tuple(metric_names) if metric_names else SUPPORTED
-        if "wfm" in metric_names:
-            raise NotImplementedError("wfm needs a distance transform over the mask; it is outside the device tail "
-                                      "(DESIGN.md §8) -- pass metric_names without 'wfm'")
         assert set(metric_names).issubset(SUPPORTED), f"Only support: {self.suppoted_metrics}"
         self.metric_names = metric_names
         self._pending: List[tuple] = []
@@ -209,16 +248,20 @@ class DeviceMetricer:
         assert pre.dtype == gt.dtype == torch.uint8, (pre.dtype, gt.dtype, gt_path)
         if not pre.is_cuda:
             raise RuntimeError("DeviceMetricer.step needs GPU tensors; there is no CPU path")
-        stats, hist = mask_counts(pre.reshape(1, *pre.shape[-2:]), gt.reshape(1, *gt.shape[-2:]))
-        self._pending.append((stats, hist, int(pre.shape[-2]), int(pre.shape[-1]), bool(same_class)))
+        p3, g3 = pre.reshape(1, *pre.shape[-2:]), gt.reshape(1, *gt.shape[-2:])
+        stats, hist = mask_counts(p3, g3)
+        wsum = mask_wfm_sums(p3, g3, hist) if "wfm" in self.metric_names else None
+        self._pending.append((stats, hist, int(pre.shape[-2]), int(pre.shape[-1]), bool(same_class), wsum))
 
     def _drain(self) -> None:
         if not self._pending:
             return
         stats = torch.cat([p[0] for p in self._pending]).cpu().numpy()
         hist = torch.cat([p[1] for p in self._pending]).cpu().numpy()
-        for i, (_, _, h, w, same) in enumerate(self._pending):
-            self._steps.append(metrics_from_counts(stats[i], hist[i], h, w, same, self.metric_names))
+        wsums = torch.cat([p[5] for p in self._pending]).cpu().numpy() if "wfm" in self.metric_names else None
+        for i, (_, _, h, w, same, _) in enumerate(self._pending):
+            self._steps.append(metrics_from_counts(stats[i], hist[i], h, w, same, self.metric_names,
+                                                   None if wsums is None else wsums[i]))
         self._pending = []
 
     def get_step_results(self) -> dict:

@@ -22,7 +22,7 @@ EXPORTS = [
     "cvlm_patchify", "cvlm_im2col3x3", "cvlm_reinterpret_transpose", "cvlm_attention", "cvlm_small_attention",
     "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
-    "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_topk_accumulate",
+    "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
 ]
 
 
@@ -323,3 +323,21 @@ def topk_accumulate(scores: torch.Tensor, labels: torch.Tensor, pred: Optional[t
     _check(load().cvlm_topk_accumulate(C.c_void_p(scores.data_ptr()), C.c_void_p(labels.data_ptr()), C.c_int32(B),
                                        C.c_int32(Cc), C.c_void_p(_p(pred)), C.c_void_p(counters.data_ptr()),
                                        C.c_void_p(_stream())), "cvlm_topk_accumulate")
+
+
+def mask_wfm_workspace_bytes(N: int, h: int, w: int) -> int:
+    return N * h * w * 16 + N * ((h * w + 255) // 256) * 24 + N * 8
+
+
+def mask_wfm(pre: torch.Tensor, gt: torch.Tensor, hist: torch.Tensor, gauss49: torch.Tensor, workspace: torch.Tensor,
+             out3: torch.Tensor) -> None:
+    """pre/gt uint8 [N][h][w], hist int32 [N][4][2][256] (from mask_joint_hist), gauss49 float64 [49],
+    workspace uint8 [>= mask_wfm_workspace_bytes], out3 float64 [N][3]."""
+    N, h, w = pre.shape
+    assert pre.dtype == torch.uint8 and gt.dtype == torch.uint8 and tuple(gt.shape) == (N, h, w)
+    assert hist.dtype == torch.int32 and gauss49.dtype == torch.float64 and gauss49.numel() == 49
+    assert out3.dtype == torch.float64 and tuple(out3.shape) == (N, 3) and workspace.numel() * workspace.element_size() >= mask_wfm_workspace_bytes(N, h, w)
+    assert pre.is_contiguous() and gt.is_contiguous() and hist.is_contiguous()
+    _check(load().cvlm_mask_wfm(C.c_void_p(pre.data_ptr()), C.c_void_p(gt.data_ptr()), C.c_int32(N), C.c_int32(h), C.c_int32(w),
+                                C.c_void_p(hist.data_ptr()), C.c_void_p(gauss49.data_ptr()), C.c_void_p(workspace.data_ptr()),
+                                C.c_void_p(out3.data_ptr()), C.c_void_p(_stream())), "cvlm_mask_wfm")

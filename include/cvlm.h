@@ -191,6 +191,15 @@ int cvlm_mask_to_u8(const float* logits, int32_t N, int32_t Hs, int32_t Ws, int3
 int cvlm_mask_joint_hist(const uint8_t* pre, const uint8_t* gt, int32_t N, int32_t h, int32_t w, uint64_t* stats, uint32_t* hist,
                          void* stream);
 
+/* Weighted F-measure ingredients (pysodmetrics 1.4.2 WeightedFmeasure.cal_wfm behind recorder/ovcos_metricer.py:49-66):
+ * exact Euclidean distance transform with nearest-foreground index (scipy's tie order), E carried over from the nearest
+ * foreground pixel, 7x7 Gaussian (gauss49: the 49 f64 weights, device memory), pixel importance, all in f64.
+ * hist = the counters of cvlm_mask_joint_hist for the same images (gives the min / max level of each mask).
+ * workspace: N*h*w*16 + N*ceil(h*w/256)*24 + N*8 bytes of device memory.  out3 f64 [N][3] = (sum Ew over gt, sum Ew over
+ * ~gt, |gt|): wfm = 2 R P / (R + P) with TPw = |gt| - out[0], P = TPw / (TPw + out[1]), R = 1 - out[0] / |gt|. */
+int cvlm_mask_wfm(const uint8_t* pre, const uint8_t* gt, int32_t N, int32_t h, int32_t w, const uint32_t* hist,
+                  const double* gauss49, void* workspace, double* out3, void* stream);
+
 /* Replaces Classification.process (recorder/new_evaluator.py:47-59): scores f32 [B][C], labels i32 [B] ->
  * pred i32 [B] (may be NULL) and counters u32 [3] += (top-1 hits, top-5 hits, rows).  Counters are NOT zeroed. */
 int cvlm_topk_accumulate(const float* scores, const int32_t* labels, int32_t B, int32_t C, int32_t* pred, uint32_t* counters,

@@ -12,8 +12,8 @@ Per-pixel numpy restatement of what the reference does after `infer_test` for on
 Pinning: `iou_changeable`, `iou_adaptive` and `Classification` are checked against the reference's code run in this
 container (tests/golden/evaltail.npz, tools/make_evaltail_golden.py).  MAE / F / E / S measures restate the published
 pysodmetrics 1.4.2 algorithm and cv2.resize restates OpenCV 4.8's float32 linear path; neither dependency is
-available here, so for those functions **parity is unpinned**.  The weighted F-measure (distance transform + 7x7
-Gaussian) is not restated.
+available here, so for those functions **parity is unpinned**.  The weighted F-measure runs on scipy's exact
+distance transform and convolution, the same routines pysodmetrics calls.
 """
 from __future__ import annotations
 
@@ -182,6 +182,39 @@ def sm(pred, gt, alpha=0.5) -> float:
         return float(max(0, alpha * obj + (1 - alpha) * reg))
 
 
+def gauss2d(shape=(7, 7), sigma=5.0) -> np.ndarray:
+    """pysodmetrics `matlab_style_gauss2D` (MATLAB fspecial('gaussian', 7, 5))."""
+    m, n = [(ss - 1) / 2 for ss in shape]
+    y, x = np.ogrid[-m:m + 1, -n:n + 1]
+    h = np.exp(-(x * x + y * y) / (2 * sigma * sigma))
+    h[h < np.finfo(h.dtype).eps * h.max()] = 0
+    sumh = h.sum()
+    if sumh != 0:
+        h /= sumh
+    return h
+
+
+def wfm(pred, gt, beta=1.0) -> float:
+    """pysodmetrics 1.4.2 `WeightedFmeasure.cal_wfm` (Margolin et al.), as called by ovcos_metricer.py:49-66 with
+    beta = 1; needs scipy (the package pysodmetrics itself builds on) for the exact Euclidean distance transform."""
+    from scipy.ndimage import convolve, distance_transform_edt as bwdist
+    if np.all(~gt):
+        return 0.0
+    dst, idxt = bwdist(gt == 0, return_indices=True)
+    e = np.abs(pred - gt)
+    et = np.copy(e)
+    et[gt == 0] = et[idxt[0][gt == 0], idxt[1][gt == 0]]
+    ea = convolve(et, weights=gauss2d((7, 7), sigma=5), mode="constant", cval=0)
+    min_e_ea = np.where(gt & (ea < e), ea, e)
+    b = np.where(gt == 0, 2 - np.exp(np.log(0.5) / 5 * dst), np.ones_like(gt, dtype=np.float64))
+    ew = min_e_ea * b
+    tpw = np.sum(gt) - np.sum(ew[gt == 1])
+    fpw = np.sum(ew[gt == 0])
+    r = 1 - np.mean(ew[gt == 1])
+    p = tpw / (tpw + fpw + _EPS)
+    return float((1 + beta) * r * p / (r + beta * p + _EPS))
+
+
 # ---- recorder/ovcos_metricer.py:126-180 (the reference's own IOU class) ---------------------------------------------
 def iou_adaptive(pred, gt) -> float:
     b = pred >= adaptive_threshold(pred)
@@ -202,7 +235,7 @@ def ovcos_metrics(pre_u8: np.ndarray, gt_u8: np.ndarray, same_class: bool = True
     predicted class differs (`:18-19`, `:36-37`, `:83-85`, `:109-111`, `:139-141`)."""
     assert pre_u8.dtype == np.uint8 and gt_u8.dtype == np.uint8 and pre_u8.shape == gt_u8.shape
     pred, gt = prepare_data(pre_u8, gt_u8)
-    out = {"sm": sm(pred, gt), "mae": mae(pred, gt), "fm_adp": fm_adaptive(pred, gt), "fm_curve": fm_changeable(pred, gt),
+    out = {"sm": sm(pred, gt), "wfm": wfm(pred, gt), "mae": mae(pred, gt), "fm_adp": fm_adaptive(pred, gt), "fm_curve": fm_changeable(pred, gt),
            "em_adp": em_adaptive(pred, gt), "em_curve": em_changeable(pred, gt), "iou_adp": iou_adaptive(pred, gt),
            "iou_curve": iou_changeable(pred, gt)}
     if not same_class:
@@ -212,7 +245,8 @@ def ovcos_metrics(pre_u8: np.ndarray, gt_u8: np.ndarray, same_class: bool = True
 
 def aggregate(steps: list) -> dict:
     """`OVCOSMetricer._get_raw_results` (ovcos_metricer.py:277-297) over a list of `ovcos_metrics` results."""
-    res = {"sm": float(np.mean([s["sm"] for s in steps])), "mae": float(np.mean([s["mae"] for s in steps]))}
+    res = {"sm": float(np.mean([s["sm"] for s in steps])), "wfm": float(np.mean([s["wfm"] for s in steps])),
+           "mae": float(np.mean([s["mae"] for s in steps]))}
     for m in ("fm", "em", "iou"):
         curve = np.stack([np.asarray(s[f"{m}_curve"], dtype=np.float64) for s in steps]).mean(axis=0)
         res[f"adp{m}"] = float(np.mean([s[f"{m}_adp"] for s in steps]))

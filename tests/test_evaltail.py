@@ -68,6 +68,7 @@ def test_counts_to_metrics_match_per_pixel_oracle(gold):
         stats, hist = _counts_numpy(pre, gt)
         for same in (True, False):
             want = M.ovcos_metrics(pre, gt, same)
+            want.pop("wfm")                                       # spatial: needs the GPU sums (test_wfm_*)
             got = E.metrics_from_counts(stats, hist, *gt.shape, same_class=same)
             assert set(got) == set(want)
             for k in want:
@@ -81,14 +82,32 @@ def test_counts_to_metrics_edge_shapes():
         for gt in (rng.integers(0, 2, (h, w)).astype(np.uint8) * 255, np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8)):
             stats, hist = _counts_numpy(pre, gt)
             want = M.ovcos_metrics(pre, gt)
+            want.pop("wfm")
             got = E.metrics_from_counts(stats, hist, h, w)
             for k in want:
                 _close(got[k], want[k], (h, w, k))
 
 
-def test_wfm_is_refused_loudly():
-    with pytest.raises(NotImplementedError):
-        E.DeviceMetricer(["a"], ("sm", "wfm"))
+def test_wfm_tail_formula_and_gaussian():
+    """host half of the weighted F-measure: the last lines of cal_wfm from three sums, and the 7x7 weights"""
+    assert E.wfm_from_sums(np.asarray([0.0, 0.0, 0.0])) == 0.0                       # empty ground truth
+    assert abs(E.wfm_from_sums(np.asarray([0.0, 0.0, 100.0])) - 1.0) < 1e-12          # perfect prediction
+    s_fg, s_bg, n1 = 12.5, 30.25, 400.0
+    r, p = 1 - s_fg / n1, (n1 - s_fg) / (n1 - s_fg + s_bg + np.spacing(1))
+    assert abs(E.wfm_from_sums(np.asarray([s_fg, s_bg, n1])) - 2 * r * p / (r + p + np.spacing(1))) < 1e-15
+    k = M.gauss2d((7, 7), 5.0)
+    assert abs(k.sum() - 1) < 1e-15 and np.allclose(k, k.T) and k[3, 3] == k.max()
+
+
+def test_wfm_oracle_edges():
+    rng = np.random.default_rng(3)
+    pre = rng.integers(0, 256, (24, 31), dtype=np.uint8)
+    assert M.ovcos_metrics(pre, np.zeros_like(pre))["wfm"] == 0.0                     # ovcos_metricer.py:56-57
+    gt = np.zeros_like(pre)
+    gt[5:15, 8:20] = 255
+    perfect = M.ovcos_metrics(gt.copy(), gt)["wfm"]
+    assert abs(perfect - 1.0) < 1e-9
+    assert 0.0 < M.ovcos_metrics(pre, gt)["wfm"] < perfect
 
 
 def test_resize_oracle_properties():
@@ -150,6 +169,34 @@ def test_joint_hist_batched_and_full_size():
         assert np.array_equal(stats[k].cpu().numpy(), ws), k
         assert np.array_equal(hist[k].cpu().numpy().astype(np.int64), wh), k
     assert int(hist.sum()) == n * h * w                                           # a checksum of checksums
+
+
+@pytest.mark.gpu
+def test_wfm_matches_scipy_based_oracle(gold):
+    """distance transform (with scipy's tie order), carried-over E, Gaussian, importance weights: all in f64 on the GPU"""
+    rng = np.random.default_rng(8)
+    cases = [(pre, gt) for _, pre, gt in _cases(gold)]
+    gt = np.where(rng.random((120, 90)) < 0.03, 255, 0).astype(np.uint8)               # scattered foreground: many EDT ties
+    cases.append((rng.integers(0, 256, gt.shape, dtype=np.uint8), gt))
+    for k, (pre, gt) in enumerate(cases):
+        p, g = _dev(pre)[None], _dev(gt)[None]
+        _, hist = E.mask_counts(p, g)
+        got = E.wfm_from_sums(E.mask_wfm_sums(p, g, hist)[0].cpu().numpy())
+        want = M.ovcos_metrics(pre, gt)["wfm"]
+        assert abs(got - want) < 1e-9, (k, got, want)
+
+
+@pytest.mark.gpu
+def test_wfm_batched_full_size():
+    rng = np.random.default_rng(12)
+    n, h, w = 2, 768, 1024
+    yy, xx = np.mgrid[0:h, 0:w]
+    gt = np.stack([np.where((yy - 300) ** 2 + (xx - 500) ** 2 < 150 ** 2, 255, 0), np.where((yy > 600) & (xx < 200), 255, 0)]).astype(np.uint8)
+    pre = np.clip(gt.astype(np.float32) * 0.8 + rng.normal(30, 25, gt.shape), 0, 255).astype(np.uint8)
+    _, hist = E.mask_counts(_dev(pre), _dev(gt))
+    sums = E.mask_wfm_sums(_dev(pre), _dev(gt), hist).cpu().numpy()
+    for k in range(n):
+        assert abs(E.wfm_from_sums(sums[k]) - M.ovcos_metrics(pre[k], gt[k])["wfm"]) < 1e-9, k
 
 
 @pytest.mark.gpu
