@@ -448,16 +448,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         int lane_x = lane;
         asm volatile("" : "+v"(lane_x));
         if (kpart > 0) {
+            __shared__ int tail_gave_up;
             if (tid == 0) {
-                int spins = 0;
+                int spins = 0, bad = 0;
                 while (__hip_atomic_load(&p.flags[tail_j * 4 + kpart - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) { atomicAdd(&p.flags[4 * 128], 1u); break; }
+                    if (++spins > (1 << 22)) { atomicAdd(&p.flags[4 * 128], 1u); bad = 1; break; }
                 }
+                tail_gave_up = bad;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
+            // a partner that never arrived must not pass for a result: the whole tile becomes NaN (fails loudly downstream)
+            const float poison = tail_gave_up ? __builtin_nanf("") : 0.f;
             const float4* slab = (const float4*)(p.ws + ((size_t)tail_j * 3 + kpart - 1) * SLAB) + (size_t)wave * MT * 4 * 64 + lane_x;
             float4 buf[2][4];
 #pragma unroll
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const float4 v = buf[mt & 1][nt];
-                    acc[mt][nt][0] += v.x; acc[mt][nt][1] += v.y; acc[mt][nt][2] += v.z; acc[mt][nt][3] += v.w;
+                    acc[mt][nt][0] += v.x + poison; acc[mt][nt][1] += v.y + poison; acc[mt][nt][2] += v.z + poison; acc[mt][nt][3] += v.w + poison;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
