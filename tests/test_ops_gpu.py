@@ -217,6 +217,27 @@ def test_attention_global_relpos(hip, G, split, hm):
     assert relerr(out.float(), ref) < (5e-6 if split == (3, 3) else 5e-3)
 
 
+def test_attention_is_deterministic_under_load(hip):
+    """Race screen for the LDS-DMA rings (counted vmcnt + raw barriers): repeated launches on a fully loaded chip
+    (B = 8 cascade shape) must reproduce the first result bit for bit."""
+    B, H, hd, G = 8, 16, 80, 64
+    D, S = H * hd, G * G
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qkv = hip.H2(torch.randn(2, B * S, 3 * D, device="cuda", generator=g).half())
+    rg = hip.H2((torch.randn(2, 2 * G - 1, hd, device="cuda", generator=g) * 0.1).half())
+    rw = hip.H2((torch.randn(2, 27, hd, device="cuda", generator=g) * 0.1).half())
+    pad = hip.H2((torch.randn(2, 3 * D, device="cuda", generator=g) * 0.1).half())
+    for kw in (dict(mode=1, grid=G, rel_h=rg, rel_w=rg), dict(mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw)):
+        outs = []
+        for _ in range(4):
+            out = hip.H2.empty(B * S, D)
+            out.t.fill_(float("nan"))
+            hip.attention(qkv, out, B, S, H, hd, split_qk=3, split_pv=3, head_major=True, **kw)
+            outs.append(out.t.clone())
+        assert not torch.isnan(outs[0].float()).any()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), kw["mode"]
+
+
 @pytest.mark.parametrize("hm", [False, True])
 @pytest.mark.parametrize("split", [(3, 3), (1, 1)])
 @pytest.mark.parametrize("G", [20, 64])
