@@ -736,8 +736,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 }  // namespace
 
 // Modelled time of a tail round cut into S chained K-parts: one part's main loop + epilogue, first slab
-// publish (~16 us), last read-back (~8 us), ~20 us per middle hop (read + publish).
-static double tail_us(int S, int K) { return 0.0685 * K / S + 14.0 + 16.0 + 8.0 + 20.0 * (S - 2); }
+// publish (~16 us), last read-back (~8 us), ~20 us per middle hop (read + publish), and the slabs of all `rem` tiles
+// moving at once (qkv at K = 1280 with 128 tail tiles measured no gain).
+static double tail_us(int S, int K, int rem) {
+    return 0.0685 * K / S + 14.0 + 16.0 + 8.0 + 20.0 * (S - 2) + 0.15 * rem;   // + concurrent hand-offs (rem slabs at once)
+}
 // Number of K-parts for a last round of `rem` tiles (1 = leave it whole).
 static int tail_parts(int rem, int K) {
     if (rem <= 0 || rem > 128) return 1;
@@ -745,7 +748,7 @@ static int tail_parts(int rem, int K) {
     int best = 1;
     double t = 0.0685 * K + 14.0;
     for (int S = 2; S <= smax; ++S)
-        if (K / 32 >= 4 * S && tail_us(S, K) < t) { t = tail_us(S, K); best = S; }
+        if (K / 32 >= 4 * S && tail_us(S, K, rem) < t) { t = tail_us(S, K, rem); best = S; }
     return best;
 }
 
@@ -835,7 +838,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             double tail = rem > 0 ? tile : 0.0;
             if (tail_env && p.a.batch == 1) {
                 const int S = tail_parts(rem, g.K);
-                if (S >= 2) tail = tail_us(S, g.K);
+                if (S >= 2) tail = tail_us(S, g.K, rem);
             }
             const double m7 = (double)(t5 / 256) * tile + tail;
             variant = (m7 <= m1 && m7 <= m2) ? 5 : (m2 <= m1 ? 2 : 1);

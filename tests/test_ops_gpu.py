@@ -95,11 +95,11 @@ def test_gemm_pixel_shuffle(hip):
 
 
 @pytest.mark.parametrize("M,N,K,why", [
-    (512, 768, 512, "6 tiles -> 4 K-parts each"),
-    (700, 1000, 1024, "ragged 3 x 4 tiles -> 4 parts, clamped rows / columns"),
+    (512, 512, 8192, "4 tiles, long K -> 4 chained K-parts each"),
+    (700, 1000, 1024, "ragged 3 x 4 tiles -> 2 parts, clamped rows / columns"),
     (4648, 1024, 4096, "CLIP c_proj: 76 tiles -> 3 parts"),
-    (256 * 33, 256 * 8, 256, "264 tiles: one full round + 8 tail tiles cut in 2 (K-tiles: 8)"),
-    (39200, 1280, 1280, "window-block proj: 770 tiles = 3 rounds + 2 tiles in 4 parts, chip fully loaded"),
+    (256 * 33, 256 * 8, 256, "264 tiles, short K: the cost model leaves the 8 tail tiles whole"),
+    (39200, 1280, 1280, "770 tiles = 3 rounds + 2 tail tiles in 2 parts, chip fully loaded"),
 ])
 def test_gemm_tail_split(hip, M, N, K, why, monkeypatch):
     """256^2 kernel with its last partial round cut along K: partial slabs handed between workgroups
