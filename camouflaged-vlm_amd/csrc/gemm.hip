@@ -883,10 +883,11 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             }
         }
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
+        else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* 256x256, 8 waves, wave groups staggered */
+#ifdef CVLM_PROBES   /* make EXTRA=-DCVLM_PROBES: the variants behind profiles/r01_gemm_probes.md and tools/{ab,trace}_gemm.py */
         else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
         else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */
         else if (variant == 6) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 0, 8);          /* same tile, mid-tile slot recycling */
-        else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* same tile, wave groups staggered */
         else if (variant == 8) CVLM_LAUNCH_D(3, 2, 2, 6, 32, 0, 8);          /* 256x128, 4 waves, one recycled slot, 2 WG/CU */
         else if (variant == 18) CVLM_LAUNCH_D(3, 2, 2, 6, 32, 1, 8);
         else if (variant == 28) CVLM_LAUNCH_D(3, 2, 2, 6, 32, 2, 8);
@@ -901,12 +902,15 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 15) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 1, 8);
         else if (variant == 25) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 2, 8);
         else if (variant == 3) CVLM_LAUNCH(3, 2, 2, 3);
+#endif
         else CVLM_LAUNCH(3, 2, 2, 2);
     } else {
         if (variant == 2) CVLM_LAUNCH(1, 4, 2, 3);
-        else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(1, 2, 2, 3, 64, 0, 4);
         else if (variant == 5) CVLM_LAUNCH_D(1, 2, 4, 3, 32, 0, 8);
+#ifdef CVLM_PROBES
+        else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(1, 2, 2, 3, 64, 0, 4);
         else if (variant == 3) CVLM_LAUNCH(1, 2, 2, 3);
+#endif
         else CVLM_LAUNCH(1, 2, 2, 2);
     }
 #undef CVLM_LAUNCH

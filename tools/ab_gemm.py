@@ -1,5 +1,6 @@
 """A/B of GEMM variants inside one process (same box, same clocks): CVLM_GEMM_VARIANT is re-read per call when
-CVLM_GEMM_VARIANT_LIVE=1.  Usage: python tools/ab_gemm.py 7 37 ..."""
+CVLM_GEMM_VARIANT_LIVE=1.  Variants other than 0 / 1 / 2 / 7 exist only in a probe build (`make -C camouflaged-vlm_amd/csrc EXTRA=-DCVLM_PROBES`).
+Usage: python tools/ab_gemm.py 7 37 ..."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CVLM_GEMM_VARIANT_LIVE"] = "1"

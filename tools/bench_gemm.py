@@ -1,4 +1,5 @@
-"""GEMM micro-benchmark on the shapes of the cascade (B = 8).  Usage: python tools/bench_gemm.py [split] [alias]"""
+"""GEMM micro-benchmark on the shapes of the cascade (B = 8).  Variants other than 0 / 1 / 2 / 7 exist only in a probe build (`make -C camouflaged-vlm_amd/csrc EXTRA=-DCVLM_PROBES`).
+Usage: python tools/bench_gemm.py [split] [alias]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from camouflaged_vlm_amd import hip

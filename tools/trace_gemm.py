@@ -1,4 +1,5 @@
 """Per-workgroup timeline of the 256x256 staggered GEMM (CVLM_GEMM_VARIANT=47): where a tile's time goes.
+Variants other than 0 / 1 / 2 / 7 exist only in a probe build (`make -C camouflaged-vlm_amd/csrc EXTRA=-DCVLM_PROBES`).
 Usage: CVLM_GEMM_VARIANT=47 python tools/trace_gemm.py"""
 import ctypes as C, os, sys, collections
 import numpy as np, torch
