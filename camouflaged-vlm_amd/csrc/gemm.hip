@@ -803,13 +803,12 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     GemmParams p;
     p.a = g;
     if (p.a.batch <= 0) p.a.batch = 1;
-    static int group_env = -1, variant_env = -1;
-    if (group_env < 0) { const char* e = getenv("CVLM_GEMM_GROUP_M"); group_env = e ? atoi(e) : 8; if (group_env < 1) group_env = 1; }
-    static int live_env = -1, tail_env = -1;
-    if (tail_env < 0 || live_env > 0) { const char* e = getenv("CVLM_GEMM_TAIL"); tail_env = e ? atoi(e) : 1; }
+    static int group_env = -1, variant_env = -1, live_env = 0, tail_env = -1;
     { const char* e = getenv("CVLM_GEMM_VARIANT_LIVE"); live_env = e ? atoi(e) : 0; }   // probes / tests: re-read the knobs per call
+    if (group_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; if (group_env < 0) group_env = 0; }
+    if (tail_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_TAIL"); tail_env = e ? atoi(e) : 1; }
     if (variant_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_VARIANT"); variant_env = e ? atoi(e) : 0; }
-    p.group_m = group_env;
+    p.group_m = 8;
     p.trace = g_trace;
     p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr; p.epoch = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -870,6 +869,10 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     int extra_blocks = 0;
     if (g.split == 3) {
         if (variant == 5 && variant_env == 0) variant = 7;      // auto: staggered wave groups (3-5 % over the plain 256^2 loop)
+        // tile rows per L2 super-tile: 8 for the small tiles; the 256^2 kernel is 2-3 % faster with 4 (2 at long K),
+        // i.e. ~20 (10) of an XCD's 32 co-resident tiles sharing their activation panels (tools/ab_gemm.py sweep)
+        if (variant == 7) p.group_m = g.K >= 4096 ? 2 : 4;
+        if (group_env > 0) p.group_m = group_env;
         if (variant == 7 && tail_env && p.a.batch == 1) {
             const long T = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
             const int rem = (int)(T % 256);
@@ -905,6 +908,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #endif
         else CVLM_LAUNCH(3, 2, 2, 2);
     } else {
+        if (group_env > 0) p.group_m = group_env;
         if (variant == 2) CVLM_LAUNCH(1, 4, 2, 3);
         else if (variant == 5) CVLM_LAUNCH_D(1, 2, 4, 3, 32, 0, 8);
 #ifdef CVLM_PROBES

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CVLM_GEMM_VARIANT_LIVE"] = "1"
 from camouflaged_vlm_amd import hip
 hip.load()
-variants = [v for v in sys.argv[1:]] or ["7"]       # "7" or "7:0" (variant:CVLM_GEMM_TAIL)
+variants = [v for v in sys.argv[1:]] or ["7"]       # "7", "7:0" (variant:CVLM_GEMM_TAIL) or "7:1:8" (..:CVLM_GEMM_GROUP_M)
 shapes = [("sam qkv", 32768, 3840, 1280), ("sam proj", 32768, 1280, 1280), ("sam lin1", 32768, 5120, 1280), ("sam lin2", 32768, 1280, 5120)]
 if os.environ.get("SHAPES") == "win":          # window blocks: 8 images x 25 windows x 196 tokens
     shapes = [("win qkv", 39200, 3840, 1280), ("win proj", 39200, 1280, 1280), ("win lin1", 39200, 5120, 1280), ("win lin2", 39200, 1280, 5120)]
@@ -20,7 +20,9 @@ for name, M, N, K in shapes:
     for rep in range(3):
         for v in variants:
             os.environ["CVLM_GEMM_VARIANT"] = v.split(":")[0]
-            os.environ["CVLM_GEMM_TAIL"] = v.split(":")[1] if ":" in v else "1"
+            f = v.split(":")
+            os.environ["CVLM_GEMM_TAIL"] = f[1] if len(f) > 1 else "1"
+            os.environ["CVLM_GEMM_GROUP_M"] = f[2] if len(f) > 2 else "0"
             hip.gemm(a, w, M, N, K, out_h2=out, split=3)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
