@@ -704,7 +704,9 @@ class Cascade(_Base):
         self.tproj = (self.dev(sd["sam_text_proj.0.weight"]), self.dev(sd["sam_text_proj.0.bias"]),
                       Linear(sd["sam_text_proj.1.weight"], sd["sam_text_proj.1.bias"], device))
         import os
-        self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "1") == "1"      # +1.3 % at B = 8 (bench.py A/B); 0 = one stream
+        # CVLM_OVERLAP_CLIP=1: CLIP pass 1 on a side stream under the SAM encoder, +1.3 % at B = 8 (same-box A/B).  Off by
+        # default: co-running kernels stretch each other's durations, which blurs the per-kernel roofline evidence.
+        self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "0") == "1"
         self._side = None
 
     def sparse_prompts(self, img_f: torch.Tensor, txt_f: torch.Tensor, B: int) -> torch.Tensor:
