@@ -347,6 +347,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         // (microarch guide, "Two waves per SIMD", item 9).  Raw s_barrier at every phase boundary; the group
         // predicate goes through readfirstlane so the extra barriers are provably wave-uniform.
         const bool grpB = __builtin_amdgcn_readfirstlane(tid) >= (NWAVE / 2) * 64;
+        constexpr bool PRIO = (DBG == 7);                              // probe: s_setprio around the MFMA groups
         const int co = chunk_off(0);
         half8 wh[4], wl[4], ah[4], al[4];
         auto mfma_half = [&](int mh, int tn, int sn) {           // 4 m-tiles; optional DMA of tile tn into slot sn
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 if (DBG != 2) {
+                    if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         floatx4 c = acc[mh * 4 + mt][nt];
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         }
                         acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
                     }
+                    if (PRIO) __builtin_amdgcn_s_setprio(0);
                 }
                 if (dma) {
                     constexpr int PP = PER_WAVE / 4;
@@ -887,6 +890,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         }
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
         else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* 256x256, 8 waves, wave groups staggered */
+#ifdef CVLM_PROBES
+        else if (variant == 77) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 7, 8);        /* probe: s_setprio around MFMA groups */
+#endif
 #ifdef CVLM_PROBES   /* make EXTRA=-DCVLM_PROBES: the variants behind profiles/r01_gemm_probes.md and tools/{ab,trace}_gemm.py */
         else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
         else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */
