@@ -348,6 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         // predicate goes through readfirstlane so the extra barriers are provably wave-uniform.
         const bool grpB = __builtin_amdgcn_readfirstlane(tid) >= (NWAVE / 2) * 64;
         constexpr bool PRIO = (DBG == 7);                              // probe: s_setprio around the MFMA groups
+        if (DBG == 8 && grpB) __builtin_amdgcn_s_setprio(1);          // probe: static priority for the younger half
         const int co = chunk_off(0);
         half8 wh[4], wl[4], ah[4], al[4];
         auto mfma_half = [&](int mh, int tn, int sn) {           // 4 m-tiles; optional DMA of tile tn into slot sn
@@ -892,6 +893,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* 256x256, 8 waves, wave groups staggered */
 #ifdef CVLM_PROBES
         else if (variant == 77) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 7, 8);        /* probe: s_setprio around MFMA groups */
+        else if (variant == 87) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 8, 8);        /* probe: static priority for waves 4..7 */
 #endif
 #ifdef CVLM_PROBES   /* make EXTRA=-DCVLM_PROBES: the variants behind profiles/r01_gemm_probes.md and tools/{ab,trace}_gemm.py */
         else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
