@@ -73,7 +73,8 @@ int cvlm_layernorm(const float* x, int64_t ldx, const float* add, int32_t add_ro
 int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, float* out_f32,
                   void* out_hi, void* out_lo, int32_t M, int32_t D, void* stream);
 
-/* f32 -> h2 planes (elementwise split), n elements. */
+/* f32 -> h2 planes (elementwise split), n elements.  No reference counterpart: it produces the operand format of
+ * cvlm_gemm / cvlm_attention from tensors the reference keeps in fp32 (e.g. the sparse prompts, models/sam_maskdecoder_edge.py:342-344). */
 int cvlm_split_f32(const float* x, void* out_hi, void* out_lo, int64_t n, void* stream);
 
 /* Patch gather for stride==kernel convolutions (image_encoder.py:651-659, :369-380;
@@ -154,7 +155,9 @@ int cvlm_clip_assemble(const float* patches, const float* cls, const float* pos,
 int cvlm_overwrite_rows(float* x, int32_t B, int32_t L, int32_t W, int32_t first, int32_t n, const float* src,
                         void* stream);
 
-/* Gather one row per sequence: out[b] = x[b][idx[b]] (idx NULL -> row `fixed`), x f32 [B][L][W]. */
+/* Gather one row per sequence: out[b] = x[b][idx[b]] (idx NULL -> row `fixed`), x f32 [B][L][W].
+ * Replaces the CLS pick `x[:, 0, :]` (alpha_clip_rw/model.py:556) and the EOT pick
+ * `x[arange, tokenized_prompts.argmax(-1)]` (cocotrainers/mapleAlphaCLIP.py:76). */
 int cvlm_gather_rows(const float* x, int32_t B, int32_t L, int32_t W, const int32_t* idx, int32_t fixed,
                      float* out, void* stream);
 
@@ -175,7 +178,9 @@ int cvlm_normalize_add(const float* x, const float* add, int32_t R, int32_t D, f
 int cvlm_resample_u8(const uint8_t* src, int32_t N, int32_t H, int32_t W, int32_t C, const int32_t* bounds,
                      const int32_t* kk, int32_t ksize, int32_t n_out, int32_t axis, uint8_t* dst, void* stream);
 
-/* ToTensor + Normalize (+ CenterCrop window): uint8 [N][H][W][C] -> f32 [N][C][ch][cw] = (x/255 - mean[c]) / std[c]. */
+/* ToTensor + Normalize (+ CenterCrop window): uint8 [N][H][W][C] -> f32 [N][C][ch][cw] = (x/255 - mean[c]) / std[c].
+ * Replaces transforms.ToTensor / Normalize of demo.py:95-97 and CenterCrop / ToTensor / Normalize of
+ * alpha_clip_rw/alpha_clip.py:83-85. */
 int cvlm_u8_to_tensor(const uint8_t* src, int32_t N, int32_t H, int32_t W, int32_t C, int32_t top, int32_t left,
                       int32_t ch, int32_t cw, const float* mean, const float* stdv, float* dst, void* stream);
 
