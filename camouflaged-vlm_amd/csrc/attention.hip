@@ -392,7 +392,10 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (g.mode == 1) {
         static int g64 = -1;
         if (g64 < 0) { const char* e = getenv("CVLM_ATTN_G64"); g64 = e ? atoi(e) : 1; }
-        if (g64 && g.grid == 64) return cvlm_attention_global64(g, s);        // 1024^2 SAM geometry fast path
+        if (g64 && (g.grid == 64 || g.grid == 96)) {                           // 1024^2 / 1536^2 SAM geometries: fast paths
+            const int rc = cvlm_attention_global64(g, s);
+            if (rc != CVLM_E_UNSUPPORTED) return rc;
+        }
         p.L = g.grid; p.LTP = g.grid | 1;
         return launch_split<80, 4, 1, false>(p, s);
     }

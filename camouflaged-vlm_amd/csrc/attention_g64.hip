@@ -264,6 +264,7 @@ int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s) {
         const int rc = cvlm_attention_global64_pp(g, s);
         if (rc != CVLM_E_UNSUPPORTED) return rc;                     // no workspace: the single-group kernel below needs none
     }
+    if (g.grid != 64) return CVLM_E_UNSUPPORTED;                     // the single-group kernel below is 64 x 64 only
     if (g.split_qk == 3 && g.split_pv == 3) return launch_g64<3, 3>(g, s);
     if (g.split_qk == 3 && g.split_pv == 1) return launch_g64<3, 1>(g, s);
     if (g.split_qk == 1 && g.split_pv == 1) return launch_g64<1, 1>(g, s);

@@ -43,9 +43,14 @@ __device__ __forceinline__ void phase_barrier() {
     asm volatile("" ::: "memory");
 }
 
+template <int L>
 __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
                                                             const half_t* __restrict__ vt_lo) {
-    constexpr int HD = 80, KS = 5, ND = 3, KP = 88, KT = 32, L = 64, LTP = 65, S = L * L, NTILE = S / KT;
+    // L = side of the token map (64: 1024^2 images, 96: 1536^2).  A key row is TPR = L / 32 tiles; the 96 map needs a
+    // 99 KB Th table, so its V ring has two slots instead of three (fetched one phase later, drained, see tile_phases)
+    constexpr int HD = 80, KS = 5, ND = 3, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, TPR = L / KT;
+    constexpr int NSV = (L == 64) ? 3 : 2;
+    static_assert(L % KT == 0 && S % 256 == 0 && NTILE % TPR == 0, "map side");
     constexpr int VROWS = 96, VROW_B = KT * 2;                       // V^T image: 96 rows (80 dims + 16 filler) x 32 keys
     constexpr int KPL_B = KT * KP * 2, VPL_B = VROWS * VROW_B;       // plane bytes: 5632 / 6144
     constexpr int KSLOT_B = 2 * KPL_B, VSLOT_B = 2 * VPL_B, NSLOT = 3;
@@ -55,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kring = smem;
     unsigned char* Vring = smem + NSLOT * KSLOT_B;
-    float* T = (float*)(Vring + NSLOT * VSLOT_B);                    // [256][LTP]  (Tw first, then Th)
+    float* T = (float*)(Vring + NSV * VSLOT_B);                      // [256][LTP]  (Tw first, then Th)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,16 +136,16 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             ql[ks] = *(const half8*)(qkv_lo + qo + 16 * ks + 8 * half);
         }
     }
-    const int qhh = qslot >> 6, qww = qslot & 63;
+    const int qhh = qslot / L, qww = qslot - qhh * L;
     float* Tq = T + (wave * 32 + qc) * LTP;
-    auto build_table = [&](const half_t* Rhi, const half_t* Rlo, int cq) {   // T[q][k] = (Q . R^T)[q][cq - k + 63]
+    auto build_table = [&](const half_t* Rhi, const half_t* Rlo, int cq) {   // T[q][k] = (Q . R^T)[q][cq - k + L - 1]
 #pragma unroll 1
-        for (int st = 0; st < 4; ++st) {
+        for (int st = 0; st < (2 * L - 1 + 31) / 32; ++st) {
             floatx16 u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) u[r] = 0.f;
             int rr = st * 32 + qc;
-            rr = rr < 127 ? rr : 126;
+            rr = rr < 2 * L - 1 ? rr : 2 * L - 2;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const half8 ah = *(const half8*)(Rhi + rr * HD + 16 * ks + 8 * half);
@@ -152,16 +157,16 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int kidx = cq + 63 - j;
-                if (j < 127 && kidx >= 0 && kidx < L) Tq[kidx] = u[r];
+                const int kidx = cq + (L - 1) - j;
+                if (j < 2 * L - 1 && kidx >= 0 && kidx < L) Tq[kidx] = u[r];
             }
         }
     };
-    f32x2 twr[2][8];                                                 // Tw[q][32*pz + (r&3) + 8*(r>>2) + 4*half], r = 2i, 2i+1
+    f32x2 twr[TPR][8];                                               // Tw[q][32*pz + (r&3) + 8*(r>>2) + 4*half], r = 2i, 2i+1
     build_table((const half_t*)g.relw_hi, (const half_t*)g.relw_lo, qww);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int pz = 0; pz < 2; ++pz)
+    for (int pz = 0; pz < TPR; ++pz)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r0 = 2 * i, r1 = 2 * i + 1;
@@ -337,26 +342,28 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
     int s0 = 0, s1 = 1, s2 = 2;                                      // t % 3, (t + 1) % 3, (t + 2) % 3
     auto tile_phases = [&](auto pz_c, int t) {
         constexpr int PZ = decltype(pz_c)::value;
+        if (NSV == 2 && grpB && t >= 1 && t + 1 < NTILE) issue_next((t + 1) & 1);   // V(t+1) into V(t-1)'s slot (read last phase)
         unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (trace) c0 = wall_clock64();
-        X(twr[PZ], Tq[t >> 1]);
+        X(twr[PZ], Tq[t / TPR]);
         if (trace) { asm volatile("" ::"v"(ph[0]), "v"(pl[1])); c1 = wall_clock64(); }
         if (!grpB) { if (t + 5 >= NTILE) wait_vm<0>(); else wait_vm<DPW>(); }
         phase_barrier();
         if (trace) c2 = wall_clock64();
         if (!grpB) { if (t + 3 < NTILE) issue_next(s0); }
-        else       { if (t + 2 < NTILE) issue_next(s2); }
-        Y(s0, s1);                                                  // the last S (tile NTILE) is computed and dropped
+        else if (NSV == 3) { if (t + 2 < NTILE) issue_next(s2); }
+        Y(NSV == 3 ? s0 : (t & 1), s1);                             // the last S (tile NTILE) is computed and dropped
         if (trace) { asm volatile("" ::"v"(s[0]), "v"(o[2][0])); c3 = wall_clock64(); }
-        if (grpB) { if (t + 5 >= NTILE) wait_vm<0>(); else wait_vm<DPW>(); }
+        if (grpB) { if (NSV == 2 || t + 5 >= NTILE) wait_vm<0>(); else wait_vm<DPW>(); }
         phase_barrier();
         if (trace) { const unsigned long long c4 = wall_clock64(); tr_x += c1 - c0; tr_xb += c2 - c1; tr_y += c3 - c2; tr_yb += c4 - c3; }
         const int n0 = s1; s1 = s2; s2 = s0; s0 = n0;
     };
 #pragma unroll 1
-    for (int t = 0; t < NTILE; t += 2) {
+    for (int t = 0; t < NTILE; t += TPR) {
         tile_phases(std::integral_constant<int, 0>{}, t);
         tile_phases(std::integral_constant<int, 1>{}, t + 1);
+        if constexpr (TPR == 3) tile_phases(std::integral_constant<int, 2>{}, t + 2);
     }
     if (!grpB) phase_barrier();                                      // match B's extra leading barrier
 
@@ -387,7 +394,8 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 // V [key][dim] (as the qkv GEMM leaves it) -> V^T [b][head][dim][key'], both planes; 64 keys x 80 dims per workgroup
 __global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g, half_t* __restrict__ vt_hi,
                                                           half_t* __restrict__ vt_lo) {
-    constexpr int HD = 80, S = 4096, TP = 88;                        // LDS row pitch in halves
+    constexpr int HD = 80, TP = 88;                                  // LDS row pitch in halves
+    const int S = g.grid * g.grid;
     __shared__ __attribute__((aligned(16))) half_t tile[2][64 * TP];
     const int tid = threadIdx.x, head = blockIdx.y, b = blockIdx.z, s0 = blockIdx.x * 64;
     const QkvStrides QS = qkv_strides(g.qkv_layout, S, g.B, g.heads, HD);
@@ -442,20 +450,29 @@ extern "C" int cvlm_debug_set_attn_g64_trace(void* buf) {
 }
 
 // exact-mode (split 3/3) fast path of cvlm_attention_global64()
-int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s) {
-    constexpr int smem = 3 * (2 * 5632) + 3 * (2 * 6144) + 256 * 65 * 4;
+template <int L>
+static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
+    constexpr int S = L * L;
+    constexpr int smem = 3 * (2 * 5632) + (L == 64 ? 3 : 2) * (2 * 6144) + 256 * (L + 1) * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr = true;
     }
-    const size_t plane = (size_t)g.B * g.heads * 80 * 4096;
+    const size_t plane = (size_t)g.B * g.heads * 80 * S;
     half_t* vt = vt_workspace(s, 2 * plane);
     if (!vt) return CVLM_E_UNSUPPORTED;                              // caller falls back to the single-wave-group kernel
-    hipLaunchKernelGGL(transpose_v_kernel, dim3(4096 / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(S / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
     CVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(attn_g64pp_kernel, dim3(4096 / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
+    hipLaunchKernelGGL(attn_g64pp_kernel<L>, dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
                        (const half_t*)(vt + plane));
     CVLM_CHECK_LAUNCH();
     return 0;
+}
+
+// exact-mode (split 3/3) global attention on a 64x64 or 96x96 token map
+int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s) {
+    if (g.grid == 64) return launch_pp<64>(g, s);
+    if (g.grid == 96) return launch_pp<96>(g, s);
+    return CVLM_E_UNSUPPORTED;
 }

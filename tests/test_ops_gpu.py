@@ -198,7 +198,7 @@ def relpos_bias(q, rel_h, rel_w, L):
 
 @pytest.mark.parametrize("hm", [False, True])
 @pytest.mark.parametrize("split", [(3, 3), (1, 1)])
-@pytest.mark.parametrize("G", [20, 64])
+@pytest.mark.parametrize("G", [20, 64, 96])
 def test_attention_global_relpos(hip, G, split, hm):
     Bn, Hh, hd = (2, 2, 80) if G == 20 else (1, 2, 80)
     D, S = Hh * hd, G * G
