@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                     s[r] = v;
                     mx = fmaxf(mx, v);
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = half_swap_max(mx);
                 const float m_new = fmaxf(m_run, mx);
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
                 const f32x2 c2 = f32x2{-m_new * LOG2E, -m_new * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
     }
 
     // ---------------- epilogue: O^T[d][q] / l -> out[token(q)][head*HD + d]
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = half_swap_sum(l_run);
     if (wave_active && qvalid && qtok >= 0) {
         const float inv = 1.0f / l_tot;
         const int64_t orow = ((int64_t)b * g.S + qtok) * D + head * HD;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_g64_kernel(const cvlm_attn_args g
             s[r] = s[r] * scale + (th + tw[r]);
             mx = fmaxf(mx, s[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = half_swap_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = exp2f((m_run - m_new) * LOG2E);
         const float mneg = m_new * LOG2E;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_g64_kernel(const cvlm_attn_args g
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = half_swap_sum(l_run);
     const float inv = 1.0f / l_tot;
     const int64_t orow = ((int64_t)b * S + qslot) * D + head * HD;
     half_t* oh = (half_t*)g.out_hi + orow;

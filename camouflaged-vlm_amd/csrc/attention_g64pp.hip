@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
         float mx = fmaxf(z[0].x, z[0].y);
 #pragma unroll
         for (int i = 1; i < 8; ++i) mx = fmaxf(fmaxf(mx, z[i].x), z[i].y);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) + th;
+        mx = half_swap_max(mx) + th;
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
         const f32x2 c2 = f32x2{(th - m_new) * LOG2E, (th - m_new) * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
     }
     if (!grpB) phase_barrier();                                      // match B's extra leading barrier
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = half_swap_sum(l_run);
     const float inv = 1.0f / l_tot;
     const int64_t orow = ((int64_t)b * S + qslot) * D + head * HD;
     half_t* oh = (half_t*)g.out_hi + orow;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
             float mx = fmaxf(s[0], s[1]);
 #pragma unroll
             for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = half_swap_max(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
             const f32x2 c2 = f32x2{-m_new * LOG2E, -m_new * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_win14_kernel(const cvlm_attn_args
     }
 
     if (trace) tr2 = wall_clock64();
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = half_swap_sum(l_run);
     if (wave_active && qvalid && qtok >= 0) {
         const float inv = 1.0f / l_tot;
         const int64_t orow = ((int64_t)b * SI + qtok) * D + head * HD;
