@@ -1,24 +1,39 @@
-"""Name -> class registry with the reference's call surface (models/models.py:7-23 of the
-reference): ``register(name)`` decorator, ``make(model_spec, args=None, load_sd=False)`` and the
-module-level ``models`` dict."""
-import copy
+"""Registry of the drop-in model classes.
 
-models = {}
+Public surface, as the reference's ``models/models.py`` offers it to ``models.make(config['model'])`` callers:
+  * ``models``            -- dict: registry name -> class
+  * ``register(name)``    -- class decorator adding an entry
+  * ``make(spec, args=None, load_sd=False)`` -- build ``spec['name']`` with ``spec['args']`` (optionally overridden by
+    ``args``) and, on request, load ``spec['sd']`` into it.
+Unknown names fail with the list of registered ones instead of a bare KeyError.
+"""
+from typing import Any, Callable, Dict, Mapping, Optional, Type
+
+models: Dict[str, Type[Any]] = {}
 
 
-def register(name):
-    def _wrap(cls):
-        models[name] = cls
+def register(name: str) -> Callable[[Type[Any]], Type[Any]]:
+    """``@register('sam')`` puts the decorated class into ``models`` under that name (last definition wins)."""
+    def add(cls: Type[Any]) -> Type[Any]:
+        models.update({name: cls})
         return cls
-    return _wrap
+    return add
 
 
-def make(model_spec, args=None, load_sd=False):
-    kwargs = model_spec['args']
-    if args is not None:
-        kwargs = copy.deepcopy(kwargs)
-        kwargs.update(args)
-    model = models[model_spec['name']](**kwargs)
+def _constructor_kwargs(spec: Mapping[str, Any], overrides: Optional[Mapping[str, Any]]) -> Dict[str, Any]:
+    merged = dict(spec.get('args') or {})            # shallow copy: the YAML dict of the caller stays untouched
+    if overrides:
+        merged.update(overrides)
+    return merged
+
+
+def make(model_spec: Mapping[str, Any], args: Optional[Mapping[str, Any]] = None, load_sd: bool = False):
+    key = model_spec['name']
+    try:
+        cls = models[key]
+    except KeyError:
+        raise KeyError(f"model {key!r} is not registered (known: {sorted(models)})") from None
+    instance = cls(**_constructor_kwargs(model_spec, args))
     if load_sd:
-        model.load_state_dict(model_spec['sd'])
-    return model
+        instance.load_state_dict(model_spec['sd'])
+    return instance
