@@ -372,6 +372,16 @@ int launch_split(const AttnParams& p, hipStream_t s) {
 int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s);       // attention_g64.hip
 int cvlm_attention_window14(const cvlm_attn_args& g, hipStream_t s);       // attention_win.hip
 
+int64_t cvlm_attention_global64_pp_workspace_bytes(const cvlm_attn_args& g);   // attention_g64pp.hip
+
+extern "C" int64_t cvlm_attention_workspace_bytes(const cvlm_attn_args* args) {
+    if (!args) return 0;
+    static int g64 = -1, pp = -1;
+    if (g64 < 0) { const char* e = getenv("CVLM_ATTN_G64"); g64 = e ? atoi(e) : 1; }
+    if (pp < 0) { const char* e = getenv("CVLM_ATTN_G64PP"); pp = e ? atoi(e) : 1; }
+    return (g64 && pp) ? cvlm_attention_global64_pp_workspace_bytes(*args) : 0;
+}
+
 extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!args || !args->qkv_hi || !args->out_hi) return CVLM_E_BADARG;
     const cvlm_attn_args& g = *args;

@@ -242,11 +242,9 @@ int launch_g64(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int NPL = (SQK == 3 || SPV == 3) ? 2 : 1;
     constexpr int smem = NPL * 32 * (88 + 96) * 2 + 128 + 128 * 65 * 4;
     auto kern = attn_g64_kernel<SQK, SPV>;
-    static bool attr = false;
-    if (!attr && smem > 48 * 1024) {
+    static bool attr[16] = {};
+    if (smem > 48 * 1024 && cvlm_first_on_device(attr))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr = true;
-    }
     hipLaunchKernelGGL(kern, dim3(4096 / 128, g.heads, g.B), dim3(256), smem, s, g);
     CVLM_CHECK_LAUNCH();
     return 0;
@@ -262,7 +260,7 @@ int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s) {
     if (pp < 0) { const char* e = getenv("CVLM_ATTN_G64PP"); pp = e ? atoi(e) : 1; }
     if (g.split_qk == 3 && g.split_pv == 3 && pp) {
         const int rc = cvlm_attention_global64_pp(g, s);
-        if (rc != CVLM_E_UNSUPPORTED) return rc;                     // no workspace: the single-group kernel below needs none
+        if (rc != CVLM_E_UNSUPPORTED) return rc;                     // incl. CVLM_E_WORKSPACE: a missing workspace is an error, not a silent fallback
     }
     if (g.grid != 64) return CVLM_E_UNSUPPORTED;                     // the single-group kernel below is 64 x 64 only
     if (g.split_qk == 3 && g.split_pv == 3) return launch_g64<3, 3>(g, s);

@@ -15,7 +15,6 @@
 //     1.13 us against 0.79 us for its 33 MFMAs alone (probe builds, tools/trace_attn_g64.py).
 //   * K and V tiles (32 keys) arrive by LDS-DMA into two three-slot rings, K running one tile ahead of V; they are
 //     issued three (K) / two (V) tiles before their first use and retired with counted vmcnt, never drained.
-#include <mutex>
 #include "common.h"
 #include "../../include/cvlm.h"
 
@@ -420,28 +419,10 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g
 
 }  // namespace
 
-// ---- V^T workspace: one per stream, grown on demand (launches on one stream are ordered)
-struct VtWs { hipStream_t stream; half_t* buf; size_t halves; };
-static VtWs g_vt[8];
-static int g_vt_n = 0;
-static std::mutex g_vt_mu;
-static half_t* vt_workspace(hipStream_t st, size_t halves) {
-    std::lock_guard<std::mutex> lk(g_vt_mu);
-    VtWs* w = nullptr;
-    for (int i = 0; i < g_vt_n; ++i)
-        if (g_vt[i].stream == st) w = &g_vt[i];
-    if (!w) {
-        if (g_vt_n == 8) return nullptr;
-        w = &g_vt[g_vt_n++];
-        *w = VtWs{st, nullptr, 0};
-    }
-    if (w->halves < halves) {
-        if (w->buf) { (void)hipStreamSynchronize(st); (void)hipFree(w->buf); }
-        w->buf = nullptr; w->halves = 0;
-        if (hipMalloc((void**)&w->buf, halves * sizeof(half_t)) != hipSuccess) return nullptr;
-        w->halves = halves;
-    }
-    return w->buf;
+// ---- V^T workspace: caller-owned (cvlm_attn_args.workspace, size from cvlm_attention_workspace_bytes())
+int64_t cvlm_attention_global64_pp_workspace_bytes(const cvlm_attn_args& g) {
+    if (g.mode != 1 || g.hd != 80 || g.split_qk != 3 || g.split_pv != 3 || (g.grid != 64 && g.grid != 96)) return 0;
+    return (int64_t)2 * g.B * g.heads * 80 * g.grid * g.grid * (int64_t)sizeof(half_t);
 }
 
 // Probe hook (not part of include/cvlm.h).
@@ -454,14 +435,12 @@ template <int L>
 static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int S = L * L;
     constexpr int smem = 3 * (2 * 5632) + (L == 64 ? 3 : 2) * (2 * 6144) + 256 * (L + 1) * 4;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[16] = {};
+    if (cvlm_first_on_device(attr))
         (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr = true;
-    }
     const size_t plane = (size_t)g.B * g.heads * 80 * S;
-    half_t* vt = vt_workspace(s, 2 * plane);
-    if (!vt) return CVLM_E_UNSUPPORTED;                              // caller falls back to the single-wave-group kernel
+    if (!g.workspace || g.workspace_bytes < cvlm_attention_global64_pp_workspace_bytes(g)) return CVLM_E_WORKSPACE;
+    half_t* vt = (half_t*)g.workspace;
     hipLaunchKernelGGL(transpose_v_kernel, dim3(S / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
     CVLM_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_g64pp_kernel<L>, dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,

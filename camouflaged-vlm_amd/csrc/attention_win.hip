@@ -349,11 +349,9 @@ int launch_win(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int smem = 2 * slot + 224 * 40 * 2 + 224 * 8 + (taug <= slot ? 0 : taug);
     const int nwx = (g.grid + 13) / 14;
     auto kern = attn_win14_kernel<SQK, SPV>;
-    static bool attr = false;
-    if (!attr && smem > 48 * 1024) {
+    static bool attr[16] = {};
+    if (smem > 48 * 1024 && cvlm_first_on_device(attr))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr = true;
-    }
     hipLaunchKernelGGL(kern, dim3(2, g.heads, g.B * nwx * nwx), dim3(256), smem, s, g, nwx);
     CVLM_CHECK_LAUNCH();
     return 0;

@@ -103,4 +103,15 @@ __device__ __forceinline__ int64_t qkv_offset(const QkvStrides& q, int b, int t,
     return b * q.sb + t * q.st + op * q.sop + head * q.sh;
 }
 
+// hipFuncSetAttribute (dynamic LDS above 48 KiB) is a per-device setting: one flag per (kernel instantiation, device).
+// Usage:  static bool once[16] = {};  if (cvlm_first_on_device(once)) hipFuncSetAttribute(...);
+static inline bool cvlm_first_on_device(bool (&done)[16]) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 15;
+    const bool first = !done[d];
+    done[d] = true;
+    return first;
+}
+
 #define CVLM_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

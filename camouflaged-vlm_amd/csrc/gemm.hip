@@ -17,7 +17,6 @@
 //
 // split == 3: acc += Whi.Ahi + Wlo.Ahi + Whi.Alo  (fp32 accumulate; ~2^-22 relative products)
 // split == 1: acc += Whi.Ahi
-#include <mutex>
 #include <type_traits>
 #include "common.h"
 #include <stdlib.h>
@@ -39,9 +38,10 @@ struct GemmParams {
     // and raise `flags` (chain: part k adds part k-1's running sum), part S-1 (highest block index) runs the epilogue.
     int tail_rem, tail_split;
     float* ws;
-    unsigned* flags;   // [tail_rem][4] arrival words (= epoch when ready), then one error word at [4 * 128]
-    unsigned epoch;
+    unsigned* flags;   // [tail_rem][4] arrival words (1 when ready; the consumer puts 0 back), then one error word at [4 * 128]
+#ifdef CVLM_PROBES
     unsigned long long* trace;   // DBG == 4 only: 8 x u64 per workgroup (timeline probe, tools/trace_gemm.py)
+#endif
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // provably wave-uniform: tile offsets stay in SGPRs
     const int wm = wave / WN, wn = wave - wm * WN;
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;
+    [[maybe_unused]] unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;   // DBG == 4 timeline stamps
     if (DBG == 4) tr0 = wall_clock64();
 
     // ---- tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
@@ -455,13 +455,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             __shared__ int tail_gave_up;
             if (tid == 0) {
                 int spins = 0, bad = 0;
-                while (__hip_atomic_load(&p.flags[tail_j * 4 + kpart - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch) {
+                while (__hip_atomic_load(&p.flags[tail_j * 4 + kpart - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
                     __builtin_amdgcn_s_sleep(8);
                     if (++spins > (1 << 22)) { atomicAdd(&p.flags[4 * 128], 1u); bad = 1; break; }
                 }
                 tail_gave_up = bad;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // this workgroup is the word's only reader: put 0 back so the next launch on this workspace (stream
+                // ordered behind this one) starts from a clean word -- no host-side epoch, safe under graph replay
+                if (!bad) __hip_atomic_store(&p.flags[tail_j * 4 + kpart - 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
             // a partner that never arrived must not pass for a result: the whole tile becomes NaN (fails loudly downstream)
@@ -500,12 +503,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&p.flags[tail_j * 4 + kpart], p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&p.flags[tail_j * 4 + kpart], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             m_lim = 0;
         }
     }
     auto trace_end = [&]() {
+#ifdef CVLM_PROBES
         if (DBG == 4 && p.trace && tid == 0) {
             const unsigned long long t3 = wall_clock64();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
             o[6] = tr3; o[7] = tr4;
         }
+#endif
     };
     if (DBG == 6) {                                                  // probe: main loop only
 #pragma unroll
@@ -525,6 +530,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     }
     // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
     const float alpha = g.alpha;
+    const float oscale = g.out_scale;                                // h2 planes carry value * oscale (launcher maps 0 -> 1)
     const bool vec_f32 = ((g.ldo & 3) == 0) && ((g.stride_o & 3) == 0);
     const bool vec_res = ((g.ldr & 3) == 0) && ((g.stride_r & 3) == 0);
     const bool vec_h = ((g.ldoh & 3) == 0) && ((g.stride_oh & 3) == 0);
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                             half8 hi, lo;
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
-                                float u = v[j];
+                                float u = v[j] * oscale;
                                 if (ACT == ACT_ABS_POST) u = fabsf(u);
                                 half_t a, b2;
                                 split_h2(u, a, b2);
@@ -722,7 +728,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             if (g.out_hi && DBG != 3) {
                 half_t hi[4], lo[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) split_h2(v[j], hi[j], lo[j]);
+                for (int j = 0; j < 4; ++j) split_h2(v[j] * oscale, hi[j], lo[j]);
                 half_t* oh = (half_t*)g.out_hi + (int64_t)z * g.stride_oh + off_h;
                 half_t* ol = g.out_lo ? (half_t*)g.out_lo + (int64_t)z * g.stride_oh + off_h : nullptr;
                 if (full && vec_h && ((off_h & 3) == 0)) {
@@ -756,43 +762,20 @@ static int tail_parts(int rem, int K) {
     return best;
 }
 
-// ---- tail-split workspaces: one per stream (launches on one stream are ordered, so one slab set per stream is enough)
-struct TailWs { hipStream_t stream; float* ws; unsigned* flags; unsigned epoch; };
-static TailWs g_tail[8];
-static int g_tail_n = 0;
-static std::mutex g_tail_mu;
+// ---- tail-split workspace (caller-owned, include/cvlm.h): [4 KiB hand-off words][128 tiles x 3 parts of 256 x 256 f32]
+constexpr size_t TAIL_FLAG_BYTES = 4096;
 constexpr size_t TAIL_WS_BYTES = (size_t)128 * 3 * 256 * 256 * sizeof(float);
-constexpr size_t TAIL_FLAG_WORDS = 4 * 128 + 1;
+static_assert((4 * 128 + 1) * sizeof(unsigned) <= TAIL_FLAG_BYTES, "hand-off words fit the flag page");
 
-static TailWs* tail_workspace(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_tail_mu);
-    for (int i = 0; i < g_tail_n; ++i)
-        if (g_tail[i].stream == st) return &g_tail[i];
-    if (g_tail_n == 8) return nullptr;
-    TailWs w{st, nullptr, nullptr, 0};
-    if (hipMalloc((void**)&w.ws, TAIL_WS_BYTES) != hipSuccess) return nullptr;
-    if (hipMalloc((void**)&w.flags, TAIL_FLAG_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(w.ws); return nullptr; }
-    if (hipMemset(w.flags, 0, TAIL_FLAG_WORDS * sizeof(unsigned)) != hipSuccess) { (void)hipFree(w.ws); (void)hipFree(w.flags); return nullptr; }
-    g_tail[g_tail_n] = w;
-    return &g_tail[g_tail_n++];
-}
+extern "C" int64_t cvlm_gemm_workspace_bytes(void) { return (int64_t)(TAIL_FLAG_BYTES + TAIL_WS_BYTES); }
 
-// Probe hook (not part of include/cvlm.h): synchronises and returns how many tail owners gave up waiting for a partner.
-extern "C" int cvlm_debug_gemm_tail_errors(void) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    unsigned total = 0;
-    std::lock_guard<std::mutex> lk(g_tail_mu);
-    for (int i = 0; i < g_tail_n; ++i) {
-        unsigned e = 0;
-        if (hipMemcpy(&e, g_tail[i].flags + 4 * 128, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        total += e;
-    }
-    return (int)total;
-}
-
+#ifdef CVLM_PROBES
 static unsigned long long* g_trace = nullptr;
 // Probe hook (not part of include/cvlm.h): device buffer of 8 x u64 per workgroup for CVLM_GEMM_VARIANT=47.
 extern "C" void cvlm_debug_set_gemm_trace(void* buf) { g_trace = (unsigned long long*)buf; }
+#endif
+
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (!args || !args->a_hi || !args->w_hi) return CVLM_E_BADARG;
@@ -807,14 +790,22 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     GemmParams p;
     p.a = g;
     if (p.a.batch <= 0) p.a.batch = 1;
-    static int group_env = -1, variant_env = -1, live_env = 0, tail_env = -1;
-    { const char* e = getenv("CVLM_GEMM_VARIANT_LIVE"); live_env = e ? atoi(e) : 0; }   // probes / tests: re-read the knobs per call
-    if (group_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_GROUP_M"); group_env = e ? atoi(e) : 0; if (group_env < 0) group_env = 0; }
-    if (tail_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_TAIL"); tail_env = e ? atoi(e) : 1; }
-    if (variant_env < 0 || live_env) { const char* e = getenv("CVLM_GEMM_VARIANT"); variant_env = e ? atoi(e) : 0; }
-    p.group_m = 8;
+    if (p.a.out_scale == 0.f) p.a.out_scale = 1.f;
+    // tuning knobs, read once per process.  A process started with CVLM_GEMM_VARIANT_LIVE=1 (tests/conftest.py,
+    // tools/ab_gemm.py) re-reads them on every call so that variants can be A/B-ed and raced inside one process.
+    static int group_env = env_int("CVLM_GEMM_GROUP_M", 0), tail_env = env_int("CVLM_GEMM_TAIL", 1),
+               variant_env = env_int("CVLM_GEMM_VARIANT", 0);
+    static const bool live_env = env_int("CVLM_GEMM_VARIANT_LIVE", 0) != 0;
+    if (live_env) {
+        group_env = env_int("CVLM_GEMM_GROUP_M", 0); tail_env = env_int("CVLM_GEMM_TAIL", 1); variant_env = env_int("CVLM_GEMM_VARIANT", 0);
+    }
+#ifdef CVLM_PROBES
     p.trace = g_trace;
-    p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr; p.epoch = 0;
+#endif
+    if (group_env < 0) group_env = 0;
+    p.group_m = 8;
+    p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr;
+    const bool have_ws = g.workspace && g.workspace_bytes >= cvlm_gemm_workspace_bytes();
     hipStream_t s = (hipStream_t)stream;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
     int variant = variant_env;
@@ -839,7 +830,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             const double tile = 0.0685 * K + 14.0;
             const int rem = (int)(t5 % 256);
             double tail = rem > 0 ? tile : 0.0;
-            if (tail_env && p.a.batch == 1) {
+            if (tail_env && have_ws && p.a.batch == 1) {
                 const int S = tail_parts(rem, g.K);
                 if (S >= 2) tail = tail_us(S, g.K, rem);
             }
@@ -863,11 +854,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         p.nbx = (g.N + WN * 64 - 1) / (WN * 64);                                                              \
         p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                            \
         auto kern_ = gemm_nt_kernel<SPLIT, WM, WN, NS, BKT, DBG, MT>;                                                     \
-        static bool attr_ = false;                                                                            \
-        if (!attr_ && smem_ > 48 * 1024) {                                                                    \
+        static bool attr_[16] = {};                                                                           \
+        if (smem_ > 48 * 1024 && cvlm_first_on_device(attr_))                                                             \
             (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_); \
-            attr_ = true;                                                                                     \
-        }                                                                                                     \
         hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby + extra_blocks, p.a.batch), dim3(WM* WN * 64), smem_, s, p); \
     } while (0)
     int extra_blocks = 0;
@@ -877,16 +866,15 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         // i.e. ~20 (10) of an XCD's 32 co-resident tiles sharing their activation panels (tools/ab_gemm.py sweep)
         if (variant == 7) p.group_m = g.K >= 4096 ? 2 : 4;
         if (group_env > 0) p.group_m = group_env;
-        if (variant == 7 && tail_env && p.a.batch == 1) {
+        if (variant == 7 && tail_env && have_ws && p.a.batch == 1) {
             const long T = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
             const int rem = (int)(T % 256);
             const int S = tail_parts(rem, g.K);
             if (S >= 2) {
-                TailWs* w = tail_workspace(s);
-                if (w) {
-                    p.tail_rem = rem; p.tail_split = S; p.ws = w->ws; p.flags = w->flags; p.epoch = ++w->epoch;
-                    extra_blocks = rem * (S - 1);
-                }
+                p.tail_rem = rem; p.tail_split = S;
+                p.flags = (unsigned*)g.workspace;
+                p.ws = (float*)((unsigned char*)g.workspace + TAIL_FLAG_BYTES);
+                extra_blocks = rem * (S - 1);
             }
         }
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);

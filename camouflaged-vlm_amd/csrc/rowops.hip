@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
 }
 
 // out[b][t][c] = xflat[b][c*T + t]: transpose of the (D x T) re-read of each image's token matrix
-__global__ __launch_bounds__(256) void reinterpret_transpose_kernel(const float* __restrict__ x, int T, int D,
+__global__ __launch_bounds__(256) void reinterpret_transpose_kernel(const float* __restrict__ x, int T, int D, float scale,
                                                                     half_t* __restrict__ out_hi,
                                                                     half_t* __restrict__ out_lo) {
     __shared__ float tile[32][33];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void reinterpret_transpose_kernel(const float*
         const int t = t0 + r, c = c0 + tx;
         if (t < T && c < D) {
             half_t h, l;
-            split_h2(tile[tx][r], h, l);
+            split_h2(tile[tx][r] * scale, h, l);
             const int64_t off = ((int64_t)b * T + t) * D + c;
             out_hi[off] = h;
             if (out_lo) out_lo[off] = l;
@@ -536,11 +536,11 @@ int cvlm_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, v
     return 0;
 }
 
-int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, void* out_hi, void* out_lo,
+int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, float scale, void* out_hi, void* out_lo,
                                void* stream) {
     if (!x || !out_hi || B <= 0 || T <= 0 || D <= 0) return CVLM_E_BADARG;
     hipLaunchKernelGGL(reinterpret_transpose_kernel, dim3((T + 31) / 32, (D + 31) / 32, B), dim3(256), 0,
-                       (hipStream_t)stream, x, T, D, (half_t*)out_hi, (half_t*)out_lo);
+                       (hipStream_t)stream, x, T, D, scale, (half_t*)out_hi, (half_t*)out_lo);
     CVLM_CHECK_LAUNCH();
     return 0;
 }

@@ -75,6 +75,15 @@ class CustomCLIP(nn.Module):
         self.test_text_features = None
         self.precision: Optional[Precision] = None
         self._engine: Optional[ClipModel] = None
+        # weights may arrive through a PARENT's load_state_dict (demo.py:89 loads the whole SAM): nn.Module recurses
+        # with _load_from_state_dict and never calls this module's load_state_dict override, but it does run the
+        # post hooks of every module it visits -- the packed engine (GEMM weights, cached text features) is dropped there
+        self.register_load_state_dict_post_hook(CustomCLIP._drop_engine_hook)
+
+    @staticmethod
+    def _drop_engine_hook(module, incompatible_keys) -> None:
+        module._engine = None
+        module._engine_text_dirty = True
 
     # ---- weights -------------------------------------------------------------------------------
     def _load_from_clip(self, clip_model) -> None:

@@ -61,6 +61,9 @@ class SAM(nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self._cascade = None
+        if hasattr(self, "clip_model"):                      # the recursion bypasses the child's override
+            self.clip_model._engine = None
+            self.clip_model._engine_text_dirty = True
         return r
 
     def _apply(self, fn, *a, **k):

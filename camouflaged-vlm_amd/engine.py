@@ -34,33 +34,58 @@ class Precision:
         return {"exact": Precision(3, 3, 3), "fast": Precision(1, 1, 1), "mixed": Precision(3, 3, 1)}[name]
 
 
+# Static power-of-two scales that keep UNBOUNDED activations inside fp16 range when they become h2 GEMM operands
+# (DESIGN.md §3): LayerNorm outputs are bounded by sqrt(D) * max|gamma| and everything downstream of them by the
+# weights; what is not bounded is (a) the raw residual stream where the reference feeds it to a Linear directly
+# (PromptGenerator.init_embeddings, image_encoder.py:278-281; the neck, :150) and (b) MLP hidden activations
+# (common.py:25, alpha_clip_rw/model.py:296-300).  Stored value = true value * scale; the consuming GEMM's alpha
+# carries 1 / scale.  Guaranteed range: |x| < 65504 / scale, i.e. 1.6e7 for the residual stream and 4.1e6 for hidden
+# units; absolute resolution of the planes 6e-8 / scale (1.5e-5 and 3.8e-6): far below the 1e-3 gate after the weights.
+X_SCALE = 2.0 ** -8
+HID_SCALE = 2.0 ** -6
+
+
 def _ceil(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
 class Workspace:
-    """Named device buffers, allocated on first use and reused across calls."""
+    """Named device buffers, reused across calls.  One flat buffer per name, sized for the largest request seen so
+    far; a request hands out a view of its head, so a changing batch size (a ragged last batch) re-uses the same
+    memory instead of keeping one full buffer set per batch size.  Peak at ViT-H 1024^2: ~0.35 GB per image.
+    Also owns the scratch memory of the two C-ABI entries that need some (include/cvlm.h: cvlm_gemm's split-K slabs,
+    cvlm_attention's transposed V).  One Workspace belongs to one engine object and is used on one stream at a time."""
 
     def __init__(self, device):
         self.device = device
-        self._f32: Dict[tuple, torch.Tensor] = {}
-        self._h2: Dict[tuple, H2] = {}
+        self._flat: Dict[tuple, torch.Tensor] = {}
+        self._gemm_ws: Optional[torch.Tensor] = None
+
+    def _get(self, kind: str, name: str, numel: int, dtype, zero: bool) -> torch.Tensor:
+        t = self._flat.get((kind, name))
+        if t is None or t.numel() < numel:
+            t = (torch.zeros if zero else torch.empty)(numel, dtype=dtype, device=self.device)
+            self._flat[(kind, name)] = t
+        return t[:numel]
 
     def f32(self, name: str, *shape: int) -> torch.Tensor:
-        key = (name,) + tuple(shape)
-        t = self._f32.get(key)
-        if t is None:
-            t = torch.empty(shape, dtype=torch.float32, device=self.device)
-            self._f32[key] = t
-        return t
+        return self._get("f32", name, int(np.prod(shape)), torch.float32, False).view(shape)
 
     def h2(self, name: str, *shape: int, zero: bool = False) -> H2:
-        key = (name,) + tuple(shape)
-        t = self._h2.get(key)
-        if t is None:
-            t = H2.zeros(*shape, device=self.device) if zero else H2.empty(*shape, device=self.device)
-            self._h2[key] = t
-        return t
+        n = int(np.prod(shape))
+        flat = self._get("h2", name, 2 * n, torch.float16, zero)
+        return H2(flat.view((2,) + tuple(shape)))
+
+    def scratch(self, name: str, nbytes: int) -> Optional[torch.Tensor]:
+        return self._get("u8", name, nbytes, torch.uint8, False) if nbytes > 0 else None
+
+    def gemm_ws(self) -> torch.Tensor:
+        if self._gemm_ws is None:
+            self._gemm_ws = hip.new_gemm_workspace(self.device)      # zero-filled once: the hand-off page starts clean
+        return self._gemm_ws
+
+    def gemm_errors(self) -> int:
+        return 0 if self._gemm_ws is None else hip.gemm_workspace_errors(self._gemm_ws)
 
 
 class Linear:
@@ -97,7 +122,11 @@ class _Base:
         alpha = kw.pop("alpha", 1.0)
         if "bias" not in kw:
             kw["bias"] = lin.bias
-        hip.gemm(a, lin.w, M, kw.pop("N", lin.N), lin.K, alpha=alpha * lin.alpha, **kw)
+        hip.gemm(a, lin.w, M, kw.pop("N", lin.N), lin.K, alpha=alpha * lin.alpha, workspace=self.ws.gemm_ws(), **kw)
+
+    def attention(self, qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, **kw) -> None:
+        hip.attention(qkv, out, B, S, heads, hd,
+                      workspace=self.ws.scratch("attn_ws", hip.attention_workspace_bytes(B, S, heads, hd, **kw)), **kw)
 
     def dev(self, t) -> torch.Tensor:
         return torch.as_tensor(t).detach().float().contiguous().to(self.device)
@@ -192,9 +221,9 @@ class SamEncoder(_Base):
             taps["patch_embed"] = x.clone()
         # :136 init_embeddings -- (T x D) matrix re-read as (D x T) and transposed (reference quirk)
         xt = ws.h2("xn", M, D)
-        hip.reinterpret_transpose(x, B, T, D, xt)
+        hip.reinterpret_transpose(x, B, T, D, xt, scale=X_SCALE)
         emb = ws.f32("emb", M, PK)
-        self.gemm(xt, self.emb_gen, M, out_f32=emb)
+        self.gemm(xt, self.emb_gen, M, out_f32=emb, alpha=1.0 / X_SCALE)
         # :137 init_handcrafted: FFT high-pass -> patch conv
         hp = self.highpass(inp)
         if taps is not None:
@@ -221,23 +250,23 @@ class SamEncoder(_Base):
             # the attention kernels stream whole cache lines instead of 160-byte slices of 7.7 KB token rows
             self.gemm(xn, blk["qkv"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim))
             if blk["window"] > 0:
-                hip.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
-                              pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
-                              head_major=True)
+                self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
+                               pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
+                               head_major=True)
             else:
-                hip.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
-                              rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
+                self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
+                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
             self.gemm(att, blk["proj"], M, residual=x, out_f32=x)
             hip.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, M, D, out_h2=xn)
-            self.gemm(xn, blk["lin1"], M, out_h2=hid, act=ACT_GELU)
-            self.gemm(hid, blk["lin2"], M, residual=x, out_f32=x)
+            self.gemm(xn, blk["lin1"], M, out_h2=hid, act=ACT_GELU, out_scale=HID_SCALE)
+            self.gemm(hid, blk["lin2"], M, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
             if taps is not None:
                 taps[f"block{i}"] = x.clone()
         # :150 neck (LayerNorm2d == row LN on NHWC)
         C = g.out_chans
-        hip.split_f32(x, xn)
+        hip.add_rows(x, None, 1, M, D, scale=X_SCALE, out_h2=xn)
         c1 = ws.f32("neck_c1", M, C)
-        self.gemm(xn, self.neck0, M, out_f32=c1)
+        self.gemm(xn, self.neck0, M, out_f32=c1, alpha=1.0 / X_SCALE)
         hip.layernorm(c1, self.nk1[0], self.nk1[1], 1e-6, M, C, out_f32=c1)
         col = ws.h2("neck_col", M, 9 * C)
         hip.im2col3x3(c1, B, G, G, C, col)
@@ -615,11 +644,11 @@ class ClipModel(_Base):
                 hip.overwrite_rows(x, Bn, L, Wd, first_row, c.n_ctx, deep[i - 1])
             hip.layernorm(x, *blk["ln1"], 1e-5, M, Wd, out_h2=xn)
             self.gemm(xn, blk["inp"], M, out_h2=qkv)
-            hip.attention(qkv, att, Bn, L, heads, Wd // heads, mode=0, causal=causal, split_qk=pr.qk, split_pv=pr.pv)
+            self.attention(qkv, att, Bn, L, heads, Wd // heads, mode=0, causal=causal, split_qk=pr.qk, split_pv=pr.pv)
             self.gemm(att, blk["out"], M, residual=x, out_f32=x)
             hip.layernorm(x, *blk["ln2"], 1e-5, M, Wd, out_h2=xn)
-            self.gemm(xn, blk["fc"], M, out_h2=hid, act=ACT_QUICKGELU)
-            self.gemm(hid, blk["pj"], M, residual=x, out_f32=x)
+            self.gemm(xn, blk["fc"], M, out_h2=hid, act=ACT_QUICKGELU, out_scale=HID_SCALE)
+            self.gemm(hid, blk["pj"], M, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
 
     def image_features(self, image: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
         """alpha_clip_rw/model.py:528-563 -> f32 [B][embed_dim] (un-normalised)."""
@@ -648,10 +677,10 @@ class ClipModel(_Base):
         c = self.c
         pre, suf = self.prefix[split], self.suffix[split]
         eot = list(int(e) for e in eot)
-        if rows is not None:
+        L, Wd = max(eot) + 1, c.text_width                        # of ALL prompts: a shard runs the same launch shapes
+        if rows is not None:                                      # per row as the full bank (bit-identical shards)
             pre, suf, eot = pre[rows], suf[rows], eot[rows]
         n = pre.shape[0]
-        L, Wd = max(eot) + 1, c.text_width
         full = torch.cat([pre, self.ctx.unsqueeze(0).expand(n, -1, -1), suf], dim=1)[:, :L].contiguous()
         x = torch.empty(n, L, Wd, device=self.device)
         hip.add_rows(full, self.tpos[:L].contiguous(), L, n * L, Wd, out_f32=x)
@@ -704,9 +733,10 @@ class Cascade(_Base):
         self.tproj = (self.dev(sd["sam_text_proj.0.weight"]), self.dev(sd["sam_text_proj.0.bias"]),
                       Linear(sd["sam_text_proj.1.weight"], sd["sam_text_proj.1.bias"], device))
         import os
-        # CVLM_OVERLAP_CLIP=1: CLIP pass 1 on a side stream under the SAM encoder, +1.3 % at B = 8 (same-box A/B).  Off by
-        # default: co-running kernels stretch each other's durations, which blurs the per-kernel roofline evidence.
-        self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "0") == "1"
+        # CLIP pass 1 runs on a side stream under the SAM encoder (+1.3 % at B = 8, same-box A/B).  CVLM_OVERLAP_CLIP=0
+        # (bench.py --no-overlap) serialises it for profiling: co-running kernels stretch each other's durations,
+        # which blurs per-kernel evidence.
+        self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "1") == "1"
         self._side = None
 
     def sparse_prompts(self, img_f: torch.Tensor, txt_f: torch.Tensor, B: int) -> torch.Tensor:

@@ -23,7 +23,9 @@ EXPORTS = [
     "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
+    "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes",
 ]
+ABI_VERSION = 2
 
 
 class GemmArgs(C.Structure):
@@ -38,6 +40,7 @@ class GemmArgs(C.Structure):
         ("alpha", C.c_float), ("act", C.c_int32), ("split", C.c_int32),
         ("ps_h", C.c_int32), ("ps_w", C.c_int32), ("ps_c2", C.c_int32),
         ("hm_S", C.c_int32), ("hm_H", C.c_int32), ("hm_hd", C.c_int32),
+        ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -49,6 +52,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("S", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
         ("mode", C.c_int32), ("grid", C.c_int32), ("window", C.c_int32), ("causal", C.c_int32),
         ("split_qk", C.c_int32), ("split_pv", C.c_int32), ("scale", C.c_float), ("qkv_layout", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -60,15 +64,18 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("CVLM_PROBE_LIB") or LIB_PATH              # CVLM_PROBE_LIB: probe builds of the same ABI (tools/)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP kernels are the only compute path of this package. "
+            f"{path} is missing: the HIP kernels are the only compute path of this package. "
             "Build them with `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950).")
-    lib = C.CDLL(os.environ.get("CVLM_PROBE_LIB") or LIB_PATH)      # CVLM_PROBE_LIB: probe builds of the same ABI (tools/)
+    lib = C.CDLL(path)
     lib.cvlm_abi_version.restype = C.c_int
     lib.cvlm_target_arch.restype = C.c_char_p
     for name in EXPORTS[2:]:
-        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).restype = C.c_int64 if name.endswith("_workspace_bytes") else C.c_int
+    if lib.cvlm_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI {lib.cvlm_abi_version()}, this binding needs {ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 
@@ -84,6 +91,28 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def _stream() -> Optional[int]:
     return torch.cuda.current_stream().cuda_stream or None
+
+
+def _on_current_device(t: torch.Tensor) -> None:
+    """Kernels launch on the CURRENT device's stream: a tensor living elsewhere would fault or silently go over xGMI
+    (one device per process is the contract, include/cvlm.h; checked on the two heavy entries)."""
+    if t.device.type != "cuda" or t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"tensor on {t.device}, current device is cuda:{torch.cuda.current_device()}: call "
+                           "torch.cuda.set_device() first (launches use the current device's stream)")
+
+
+def gemm_workspace_bytes() -> int:
+    return int(load().cvlm_gemm_workspace_bytes())
+
+
+def new_gemm_workspace(device) -> torch.Tensor:
+    """Zero-filled (the 4-KiB hand-off page must start at zero, include/cvlm.h) split-K workspace for cvlm_gemm."""
+    return torch.zeros(gemm_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def gemm_workspace_errors(ws: torch.Tensor) -> int:
+    """Abandoned split-K hand-offs recorded in a workspace (word 512; synchronises).  0 in a healthy run."""
+    return int(ws[2048:2052].view(torch.int32).item())
 
 
 class H2:
@@ -136,7 +165,9 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          ldoh: Optional[int] = None, alpha: float = 1.0, act: int = ACT_NONE, split: int = 3, batch: int = 1,
          stride_a: int = 0, stride_w: int = 0, stride_r: int = 0, stride_o: int = 0, stride_oh: int = 0,
          pixel_shuffle: Optional[Tuple[int, int, int]] = None,
-         head_major: Optional[Tuple[int, int, int]] = None) -> None:
+         head_major: Optional[Tuple[int, int, int]] = None, out_scale: float = 1.0,
+         workspace: Optional[torch.Tensor] = None) -> None:
+    _on_current_device(a.t)
     g = GemmArgs()
     g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
     g.w_hi, g.w_lo, g.ldw, g.stride_w = w.hi.data_ptr(), w.lo.data_ptr(), ldw if ldw is not None else K, stride_w
@@ -152,6 +183,9 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
         g.ps_h, g.ps_w, g.ps_c2 = pixel_shuffle
     if head_major is not None:
         g.hm_S, g.hm_H, g.hm_hd = head_major
+    g.out_scale = out_scale
+    if workspace is not None:
+        g.workspace, g.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     _check(load().cvlm_gemm(C.byref(g), C.c_void_p(_stream())), "cvlm_gemm")
 
 
@@ -196,15 +230,19 @@ def im2col3x3(x: torch.Tensor, B: int, H: int, W: int, Cc: int, out: H2) -> None
            "cvlm_im2col3x3")
 
 
-def reinterpret_transpose(x: torch.Tensor, B: int, T: int, D: int, out: H2) -> None:
+def reinterpret_transpose(x: torch.Tensor, B: int, T: int, D: int, out: H2, scale: float = 1.0) -> None:
     _check(load().cvlm_reinterpret_transpose(C.c_void_p(x.data_ptr()), C.c_int32(B), C.c_int32(T), C.c_int32(D),
-                                             C.c_void_p(out.hi.data_ptr()), C.c_void_p(out.lo.data_ptr()),
+                                             C.c_float(scale), C.c_void_p(out.hi.data_ptr()), C.c_void_p(out.lo.data_ptr()),
                                              C.c_void_p(_stream())), "cvlm_reinterpret_transpose")
 
 
 def attention(qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, *, mode: int = 0, grid: int = 0, window: int = 0,
               causal: bool = False, pad: Optional[H2] = None, rel_h: Optional[H2] = None, rel_w: Optional[H2] = None,
-              split_qk: int = 3, split_pv: int = 3, scale: Optional[float] = None, head_major: bool = False) -> None:
+              split_qk: int = 3, split_pv: int = 3, scale: Optional[float] = None, head_major: bool = False,
+              workspace: Optional[torch.Tensor] = None) -> None:
+    """workspace: uint8 tensor of >= attention_workspace_bytes(...) bytes for the modes that need one; when omitted a
+    temporary is taken from torch's allocator (stream-ordered, so it may be released right after the launch)."""
+    _on_current_device(qkv.t)
     a = AttnArgs()
     a.qkv_hi, a.qkv_lo = qkv.hi.data_ptr(), qkv.lo.data_ptr()
     if pad is not None:
@@ -218,7 +256,20 @@ def attention(qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, *, mode: in
     a.split_qk, a.split_pv = split_qk, split_pv
     a.scale = float(hd) ** -0.5 if scale is None else scale
     a.qkv_layout = int(head_major)
+    need = int(load().cvlm_attention_workspace_bytes(C.byref(a)))
+    if need > 0:
+        if workspace is None or workspace.numel() * workspace.element_size() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=qkv.t.device)
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     _check(load().cvlm_attention(C.byref(a), C.c_void_p(_stream())), "cvlm_attention")
+
+
+def attention_workspace_bytes(B: int, S: int, heads: int, hd: int, *, mode: int = 0, grid: int = 0, split_qk: int = 3,
+                              split_pv: int = 3, **_unused) -> int:
+    """Bytes of caller-owned scratch cvlm_attention wants for these arguments (0 for most modes)."""
+    a = AttnArgs()
+    a.B, a.S, a.heads, a.hd, a.mode, a.grid, a.split_qk, a.split_pv = B, S, heads, hd, mode, grid, split_qk, split_pv
+    return int(load().cvlm_attention_workspace_bytes(C.byref(a)))
 
 
 def small_attention(q, k, v, out, B: int, nq: int, nk: int, heads: int, hd: int) -> None:

@@ -103,3 +103,24 @@ def make_inputs(g: SamGeometry, c: ClipGeometry, batch: int, seed: int = 0, inde
         clip_image[b] = _normal(f"input.clip_image.{index0 + b}", seed, (3, R, R))
     clip_mask = np.full((batch, 1, R, R), (1.0 - 0.5) / 0.26, np.float32)
     return inp, clip_image, clip_mask
+
+
+def apply_outliers(sd: Dict[str, np.ndarray], prefix: str = "image_encoder.") -> Dict[str, np.ndarray]:
+    """Copy of ``sd`` with a few SAM-encoder channels pushed far outside O(1), the way real ViT checkpoints look
+    (tests/golden/tiny_outliers.npz is the reference's output on these weights):
+
+      * residual stream: patch-embed output channels 3 and 77 x 1e3, channel 40 x 1e4  ("massive" channels that
+        every block carries; LayerNorm then squeezes the ordinary channels to ~1e-2)
+      * one dead channel: patch-embed output channel 11 x 1e-6
+      * one hot MLP unit: block 1 lin1 row 5 x 1e4 (hidden activation ~1e4, lands on every residual channel
+        through lin2), block 2 lin1 row 9 x 1e3
+    """
+    out = {k: v.copy() for k, v in sd.items()}
+    pw, pb = prefix + "patch_embed.proj.weight", prefix + "patch_embed.proj.bias"
+    for ch, f in ((3, 1e3), (77, 1e3), (40, 1e4), (11, 1e-6)):
+        out[pw][ch] *= f
+        out[pb][ch] *= f
+    for blk, row, f in ((1, 5, 1e4), (2, 9, 1e3)):
+        out[f"{prefix}blocks.{blk}.mlp.lin1.weight"][row] *= f
+        out[f"{prefix}blocks.{blk}.mlp.lin1.bias"][row] *= f
+    return out

@@ -7,7 +7,12 @@
  * root) whose arithmetic it replaces.  Conventions:
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
  *   - launchers never allocate, never synchronise, never retain pointers; `stream` is a hipStream_t
- *     passed as void* (NULL = default stream); workspace is caller-owned;
+ *     passed as void* (NULL = default stream) and must belong to the CURRENT device (one device per process is the
+ *     intended use; a process driving several devices calls hipSetDevice before each launch);
+ *   - workspace is caller-owned: the two entries that need scratch memory (cvlm_gemm, cvlm_attention) take a
+ *     `workspace` pointer + size in their argument structs and publish the size they want through
+ *     cvlm_gemm_workspace_bytes() / cvlm_attention_workspace_bytes().  A workspace must not be shared by launches
+ *     that can run concurrently (different streams);
  *   - return value: 0 on success, otherwise a hipError_t value or a negative CVLM_E_* code;
  *   - tensors are row-major.  "f32" = float.  "h2" = split-half pair: two fp16 planes (hi, lo) of
  *     identical shape, value = hi + lo; `lo` may be NULL where noted (fast mode, split = 1).
@@ -19,9 +24,10 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 1
+#define CVLM_ABI_VERSION 2
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
+#define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
 
 enum { CVLM_ACT_NONE = 0, CVLM_ACT_GELU = 1, CVLM_ACT_QUICKGELU = 2, CVLM_ACT_RELU = 3, CVLM_ACT_ABS_POST = 4 };
 
@@ -41,6 +47,14 @@ const char* cvlm_target_arch(void);
  * store used for ConvTranspose2d(k=2,s=2): row m = (b,y,x) on a ps_h x ps_w grid, column
  * n = dy*ps_c2 + r  ->  out[((b*2*ps_h + 2y+dy) * 2*ps_w + 2x) * (ps_c2/2) + r].
  * batch > 1 runs `batch` independent problems with the given element strides (0 = shared).
+ * out_scale (0 = 1): the h2 output is stored as value * out_scale (a power of two keeps it exact); the consumer folds
+ * 1 / out_scale into its alpha.  It moves an unbounded activation (the GELU output of common.py:25) into fp16 range.
+ * workspace: optional scratch of cvlm_gemm_workspace_bytes() bytes.  With it, a grid of 256 x 256 tiles whose last
+ * round fills at most half the chip has the tiles of that round cut along K and reduced through fp32 slabs in the
+ * workspace (fixed summation order); without it every tile is computed whole (same result up to fp32 summation
+ * order, slower for 2.5-round shapes).  The first 4 KiB of the workspace are hand-off words: zero them ONCE after
+ * allocation (hipMemset); kernels leave them zero.  Word 512 counts abandoned hand-offs (a partner workgroup that
+ * never arrived; the affected tile is written as NaN): 0 in a healthy run.
  */
 typedef struct cvlm_gemm_args {
     const void* a_hi; const void* a_lo; int64_t lda; int64_t stride_a;
@@ -55,8 +69,12 @@ typedef struct cvlm_gemm_args {
     int32_t split;
     int32_t ps_h, ps_w, ps_c2;
     int32_t hm_S, hm_H, hm_hd;   /* hm_S > 0: h2 output stored head-major [3][M/hm_S][hm_H][hm_S][hm_hd] (qkv for cvlm_attention layout 1) */
+    float out_scale;             /* ABI 2 */
+    void* workspace;             /* ABI 2 */
+    int64_t workspace_bytes;     /* ABI 2 */
 } cvlm_gemm_args;
 int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
+int64_t cvlm_gemm_workspace_bytes(void);
 
 /* Row LayerNorm over the last axis: y = LN(x + add) * gamma + beta, biased variance, then act.
  * Replaces nn.LayerNorm (image_encoder.py:432,444; alpha_clip_rw/model.py:162-168;
@@ -92,8 +110,9 @@ int cvlm_im2col3x3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, v
 
 /* Matrix transpose-reinterpretation used by PromptGenerator.init_embeddings (image_encoder.py:278-281):
  * per image, the (T x D) f32 token matrix is re-read as (D x T) and transposed:
- * out[b][t][c] = x_flat[b][c*T + t].  Output h2 [B*T][D]. */
-int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, void* out_hi, void* out_lo,
+ * out[b][t][c] = scale * x_flat[b][c*T + t].  Output h2 [B*T][D].  (scale: a power of two that moves the raw
+ * residual stream into fp16 range; the consuming GEMM folds 1 / scale into its alpha.) */
+int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, float scale, void* out_hi, void* out_lo,
                                void* stream);
 
 /* Fused multi-head attention (flash style, scores never materialised), replaces
@@ -107,7 +126,9 @@ int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, 
  * mode 2: windows of `window` x `window` tokens on a grid x grid map, zero padded: pad tokens carry
  *         q = k = v = qkv bias (pad_hi/pad_lo = h2 of the 3*heads*hd bias vector).
  * rel_h/rel_w: h2 [(2*L-1)][hd] tables (L = grid or window).  scale = hd^-0.5 applied to q.k only.
- * out: h2 [B*S_img][heads*hd]. */
+ * out: h2 [B*S_img][heads*hd].
+ * workspace: the exact-mode (split 3/3) global kernels for the 64x64 and 96x96 maps keep V transposed
+ * (cvlm_attention_workspace_bytes(args) bytes, 0 for every other mode); CVLM_E_WORKSPACE if it is missing there. */
 typedef struct cvlm_attn_args {
     const void* qkv_hi; const void* qkv_lo;
     const void* pad_hi; const void* pad_lo;
@@ -119,8 +140,11 @@ typedef struct cvlm_attn_args {
     int32_t split_qk, split_pv;
     float scale;
     int32_t qkv_layout;          /* 0: token-major [B*S][3][H][hd]; 1: head-major [3][B][H][S][hd] */
+    void* workspace;             /* ABI 2 */
+    int64_t workspace_bytes;     /* ABI 2 */
 } cvlm_attn_args;
 int cvlm_attention(const cvlm_attn_args* args, void* stream);
+int64_t cvlm_attention_workspace_bytes(const cvlm_attn_args* args);
 
 /* Small fp32 attention for the two-way decoder (transformer_maskdecoder_edge.py:250-272):
  * q f32 [B][nq][heads*hd] (ldq), k,v f32 [B][nk][heads*hd]; out f32 [B][nq][heads*hd].

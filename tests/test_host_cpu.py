@@ -25,7 +25,56 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/cvlm.h but not exported"
     assert set(hip.EXPORTS) == declared
-    assert lib.cvlm_abi_version() == 1 and lib.cvlm_target_arch() == b"gfx950"
+    assert lib.cvlm_abi_version() == hip.ABI_VERSION == 2 and lib.cvlm_target_arch() == b"gfx950"
+
+
+def test_integration_doc_struct_matches_binding():
+    """INTEGRATION.md prints the ctypes struct a reference maintainer would copy: it must have the layout of the real
+    binding (a short struct makes the library read past its end)."""
+    import ctypes
+    from camouflaged_vlm_amd import hip
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    m = re.search(r"class cvlm_attn_args\(ctypes\.Structure\):.*?\n(?=\ndef )", doc, re.S)
+    assert m, "struct block not found in INTEGRATION.md"
+    ns = {"ctypes": ctypes}
+    exec(m.group(0), ns)
+    doc_struct = ns["cvlm_attn_args"]
+    assert ctypes.sizeof(doc_struct) == ctypes.sizeof(hip.AttnArgs)
+    assert [(n, getattr(doc_struct, n).offset) for n, _ in doc_struct._fields_] == \
+           [(n, getattr(hip.AttnArgs, n).offset) for n, _ in hip.AttnArgs._fields_]
+    # and the binding mirrors the header: every field name of the C struct, in order
+    hdr = open(os.path.join(REPO, "include", "cvlm.h")).read()
+    for cname, cls in (("cvlm_attn_args", hip.AttnArgs), ("cvlm_gemm_args", hip.GemmArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = decl.split(",")
+            names.append(re.findall(r"[A-Za-z_0-9]+", first)[-1])
+            names += [re.findall(r"[A-Za-z_0-9]+", r)[-1] for r in rest]
+        assert names == [n for n, _ in cls._fields_], cname
+
+
+def test_clip_engine_dropped_when_parent_loads_weights():
+    """nn.Module.load_state_dict on a parent recurses without calling the child's override; the packed
+    CLIP engine must still be dropped (post hook)."""
+    sys.path.insert(0, cv.DROPIN_DIR)
+    from cocotrainers.mapleAlphaCLIP import CustomCLIP
+    c = spec.TINY_CLIP
+    clip = CustomCLIP(geometry=c, eot_train=[3] * c.n_cls_train, eot_test=[3] * c.n_cls_test)
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.clip_model = clip
+
+    par = Parent()
+    clip._engine, clip._engine_text_dirty = "stale", False
+    par.load_state_dict(par.state_dict(), strict=True)
+    assert clip._engine is None and clip._engine_text_dirty is True
 
 
 def test_bad_arguments_return_error_codes_without_gpu():

@@ -104,29 +104,26 @@ def test_gemm_pixel_shuffle(hip):
 def test_gemm_tail_split(hip, M, N, K, why, monkeypatch):
     """256^2 kernel with its last partial round cut along K: partial slabs handed between workgroups
     (possibly across XCDs) must be complete and fresh, whichever order the partners finish in."""
-    import ctypes
-    monkeypatch.setenv("CVLM_GEMM_VARIANT_LIVE", "1")
     monkeypatch.setenv("CVLM_GEMM_VARIANT", "7")
     monkeypatch.setenv("CVLM_GEMM_TAIL", "1")
+    ws = hip.new_gemm_workspace("cuda")                                                # caller-owned slabs + hand-off words
     a, w, bias = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=0.05), rnd(N, seed=63)
     A, W = dev_h2(hip, a), dev_h2(hip, w)
     ref = A.float().double() @ W.float().double().t() + bias.cuda().double()            # on the GPU: 39200-row case
     outs = []
-    for rep in range(3):                                                               # epochs advance, slabs are reused
+    for rep in range(3):                                                               # slabs and hand-off words are reused
         out = torch.full((M, N), float("nan"), device="cuda")
         oh = hip.H2.empty(M, N)
-        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=out, out_h2=oh)
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=out, out_h2=oh, workspace=ws)
         outs.append(out)
         assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6, why
         assert float((oh.float().double() - ref).abs().max() / ref.abs().max()) < 2e-6, why
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])             # fixed summation order
-    monkeypatch.setenv("CVLM_GEMM_TAIL", "0")
     plain = torch.empty(M, N, device="cuda")
-    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=plain)
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=plain)                           # no workspace: every tile whole
     assert float((plain - outs[0]).abs().max() / ref.abs().max()) < 4e-6               # same values up to fp32 sum order
-    lib = hip.load()
-    lib.cvlm_debug_gemm_tail_errors.restype = ctypes.c_int
-    assert lib.cvlm_debug_gemm_tail_errors() == 0
+    assert hip.gemm_workspace_errors(ws) == 0                                          # no abandoned hand-off
+    assert int(ws[:2048].view(torch.int32).abs().sum()) == 0                           # hand-off words are back to zero
 
 
 def to_head_major(qkv, Bn, S, Hh, hd):

@@ -98,3 +98,20 @@ def test_plain_sam_entry_matches_reference(golden_dir):
     assert m.shape == gp["mask_logits"].shape
     assert d(m, gp["mask_logits"]) < 2e-5
     assert O.mask_iou(m.numpy(), gp["mask_logits"]) >= 0.9999
+
+
+def test_oracle_matches_reference_on_outlier_weights(golden_dir):
+    """The oracle against the reference run on synth.apply_outliers weights (massive residual channels, hot MLP units)."""
+    from camouflaged_vlm_amd import spec, synth
+    from oracle import cvlm_oracle as O
+    with np.load(os.path.join(golden_dir, "tiny_outliers.npz")) as z:
+        go = {k: z[k] for k in z.files}
+    g, c = spec.TINY_SAM, spec.TINY_CLIP
+    sd = O.to_torch_sd(synth.apply_outliers(synth.make_full_state_dict(g, c)))
+    inp, ci, cm = (torch.from_numpy(t) for t in synth.make_inputs(g, c, batch=2))
+    with torch.no_grad():
+        tf = O.clip_text_features(sd, c, go["eot_test"].tolist())
+        m, p, l = O.cascade(inp, ci, cm, sd, g, c, tf, torch.from_numpy(go["bank_test"]))
+    assert float((m - torch.from_numpy(go["mask_logits"])).abs().max()) < 1e-4
+    assert float((l - torch.from_numpy(go["class_logits"])).abs().max()) < 1e-4
+    assert p.tolist() == go["pred"].tolist()

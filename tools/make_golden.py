@@ -218,6 +218,78 @@ def demo_digest(out_dir, mods, n_images=1):
     print("demo: %d image(s) in %.1f s; mask std %.3f; pred %s" % (n_images, dt, masks.std(), preds))
 
 
+def outlier_weights(sd):
+    """Round 2, VERDICT item 6: the synthetic weights with a few channels pushed far outside O(1) -- what real ViT
+    checkpoints look like (massive residual channels, one hot MLP unit, one dead channel).  Pure function of the
+    synthetic state_dict so that the GPU test rebuilds exactly the same weights (camouflaged_vlm_amd.synth)."""
+    return synth.apply_outliers(sd)
+
+
+def tiny_outliers(out_dir, mods):
+    """Tiny cascade on the outlier weights: masks / logits of the reference for tests/test_cascade_gpu.py."""
+    mm, ml, cm, train_names, test_names = mods
+    g, c = spec.TINY_SAM, spec.TINY_CLIP
+    model, sd, eot_train, eot_test = build_reference(mm, ml, cm, g, c, train_names, test_names)
+    sd2 = outlier_weights(sd)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()}, strict=True)
+    inp, clip_image, clip_mask = synth.make_inputs(g, c, batch=2)
+    taps = {}
+    hooks = []
+    enc = model.image_encoder
+    for name, mod, fn in (("patch_embed", enc.patch_embed, lambda o: o), ("block0", enc.blocks[0], lambda o: o),
+                          ("block3", enc.blocks[3], lambda o: o), ("features", enc, lambda o: o[0])):
+        def hook(m, i, o, name=name, fn=fn):
+            if name not in taps:
+                taps[name] = fn(o).detach().numpy().copy()
+        hooks.append(mod.register_forward_hook(hook))
+    masks, preds, logits, logits1 = run_reference(model, inp, clip_image, clip_mask, c.image_resolution)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(
+        os.path.join(out_dir, "tiny_outliers.npz"),
+        mask_logits=masks.astype(np.float32), pred=preds.astype(np.int64), class_logits=logits.astype(np.float32),
+        pass1_logits=logits1.astype(np.float32), eot_test=eot_test, bank_test=model.test_text_features.numpy(),
+        **{"tap_" + k: v.astype(np.float32) for k, v in taps.items()})
+    print("outliers: |patch_embed| max %.3e, |block0| max %.3e, |block3| max %.3e; mask std %.3f min %.3f max %.3f | pred %s" %
+          (np.abs(taps["patch_embed"]).max(), np.abs(taps["block0"]).max(), np.abs(taps["block3"]).max(),
+           masks.std(), masks.min(), masks.max(), preds))
+
+
+def hires_digest(out_dir, mods):
+    """BASELINE configs[4] at its stated size: the reference's ImageEncoderViT *built* at 1536^2 with ViT-H width
+    (96x96 tokens, S = 9216 global attention, 191-row rel-pos tables), image 0 -> digest of the (1,256,96,96) output."""
+    import dataclasses
+    import importlib
+    import time
+    from functools import partial
+    g = dataclasses.replace(spec.DEMO_SAM, inp_size=1536)
+    ie = importlib.import_module("models.mmseg.models.sam.image_encoder")
+    enc = ie.ImageEncoderViT(depth=g.depth, embed_dim=g.embed_dim, img_size=g.inp_size, mlp_ratio=g.mlp_ratio,
+                             norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=g.num_heads,
+                             patch_size=g.patch_size, qkv_bias=True, use_rel_pos=True,
+                             global_attn_indexes=list(g.global_attn_indexes), window_size=g.window_size,
+                             out_chans=g.out_chans)
+    sd = synth.make_state_dict(spec.sam_encoder_entries(g))
+    ref_keys = set(enc.state_dict().keys())
+    mine = {k[len("image_encoder."):]: v for k, v in sd.items()}
+    assert ref_keys == set(mine.keys()), (sorted(ref_keys - set(mine))[:8], sorted(set(mine) - ref_keys)[:8])
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in mine.items()}, strict=True)
+    enc.eval()
+    inp = synth.make_inputs(g, spec.DEMO_CLIP, batch=1)[0]
+    t0 = time.time()
+    with torch.no_grad():
+        out = enc(torch.from_numpy(inp))
+    out = (out[0] if isinstance(out, (tuple, list)) else out).numpy()
+    dt = time.time() - t0
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, out.size, size=16384)
+    np.savez_compressed(os.path.join(out_dir, "hires1536_digest.npz"), shape=np.array(out.shape), sample_idx=idx,
+                        samples=out.reshape(-1)[idx].astype(np.float32),
+                        stats=np.array([out.mean(), out.std(), out.min(), out.max()], np.float64),
+                        channel_mean=out.mean(axis=(0, 2, 3)).astype(np.float32), ref_seconds=np.array(dt))
+    print("hires1536: encoder output %s in %.1f s; std %.4f min %.3f max %.3f" % (out.shape, dt, out.std(), out.min(), out.max()))
+
+
 def sam_plain(out_dir, mods):
     """Registry entry ``sam`` (models/sam.py:298-440): encoder + vanilla MaskDecoder, no prompts -> `infer` masks."""
     import importlib
@@ -259,12 +331,20 @@ if __name__ == "__main__":
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
     ap.add_argument("--demo-digest", action="store_true")
     ap.add_argument("--only-sam-plain", action="store_true")
+    ap.add_argument("--only-outliers", action="store_true")
+    ap.add_argument("--only-hires-digest", action="store_true")
     ap.add_argument("--skip-tiny", action="store_true")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     mods = install_reference()
     if args.only_sam_plain:
         sam_plain(args.out, mods)
+        sys.exit(0)
+    if args.only_outliers:
+        tiny_outliers(args.out, mods)
+        sys.exit(0)
+    if args.only_hires_digest:
+        hires_digest(args.out, mods)
         sys.exit(0)
     tokens(args.out, mods)
     if not args.skip_tiny:
