@@ -165,6 +165,16 @@ class SamEncoder(_Base):
         self.light = [L(f"{pg}lightweight_mlp_{i}.0", n_pad=self.PK, k_pad=self.PK) for i in range(g.depth)]
         lr, li = lowpass_matrices(g.inp_size, g.fft_halfwidth)
         self.lstack = H2(H2.pack(torch.cat([lr, li], 0)).t.to(device))       # [2N][N]
+        # Prompt fold: x_{i+1} = x_i + lin2_i(hid) + shared_mlp(prm_{i+1}) is ONE contraction over K = mlp_dim + PK,
+        #   [hid | prm_{i+1}] . [W2_i | W_shared]^T + (b2_i + b_shared) + x_i,
+        # so the adapter's per-block `x = prompt_i + x` (image_encoder.py:145) costs 1.25 % more MLP FLOPs instead of
+        # a separate pass that reads and rewrites the whole residual stream (168 MB at B = 8, 32 times).
+        shw = torch.zeros(D, self.PK)
+        shw[:, :Pd] = sd[P + pg + "shared_mlp.weight"].detach().float().cpu()
+        shb = sd[P + pg + "shared_mlp.bias"].detach().float().cpu()
+        self.lin2cat = [Linear(torch.cat([sd[P + f"blocks.{i}.mlp.lin2.weight"].detach().float().cpu(), shw], 1),
+                               sd[P + f"blocks.{i}.mlp.lin2.bias"].detach().float().cpu() + shb, device)
+                        for i in range(g.depth - 1)]
         self.blocks = []
         for i in range(g.depth):
             b = f"blocks.{i}."
@@ -239,11 +249,15 @@ class SamEncoder(_Base):
         qkv = ws.h2("qkv", M, 3 * D)
         att = ws.h2("att", M, D)
         prm = ws.h2("prm", M, PK)
-        hid = ws.h2("hid", M, g.mlp_dim)
+        HK = g.mlp_dim + PK                                        # hidden row: [GELU(lin1) | prm of the NEXT block]
+        hid = ws.h2("hid", M, HK)
+        hid_prm = H2(hid.t[:, :, g.mlp_dim:])                      # the PK trailing columns (same row pitch)
+        fold = taps is None                                        # block taps need x before the next prompt is added
         for i, blk in enumerate(self.blocks):
             # :138/:145 prompt_i = shared_mlp(GELU(lightweight_mlp_i(feat))) ; x = prompt_i + x
-            self.gemm(feat, self.light[i], M, out_h2=prm, act=ACT_GELU)
-            self.gemm(prm, self.shared, M, residual=x, out_f32=x)
+            if i == 0 or not fold:
+                self.gemm(feat, self.light[i], M, out_h2=prm, act=ACT_GELU)
+                self.gemm(prm, self.shared, M, residual=x, out_f32=x)
             # :430-446 block
             hip.layernorm(x, blk["n1w"], blk["n1b"], 1e-6, M, D, out_h2=xn)
             # qkv is stored head-major [3][B][H][T][hd]: every (image, head) K / V matrix is contiguous, so
@@ -258,8 +272,12 @@ class SamEncoder(_Base):
                                rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
             self.gemm(att, blk["proj"], M, residual=x, out_f32=x)
             hip.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, M, D, out_h2=xn)
-            self.gemm(xn, blk["lin1"], M, out_h2=hid, act=ACT_GELU, out_scale=HID_SCALE)
-            self.gemm(hid, blk["lin2"], M, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
+            self.gemm(xn, blk["lin1"], M, out_h2=hid, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE)
+            if fold and i + 1 < g.depth:
+                self.gemm(feat, self.light[i + 1], M, out_h2=hid_prm, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE)
+                self.gemm(hid, self.lin2cat[i], M, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
+            else:
+                self.gemm(hid, blk["lin2"], M, lda=HK, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
             if taps is not None:
                 taps[f"block{i}"] = x.clone()
         # :150 neck (LayerNorm2d == row LN on NHWC)

@@ -236,7 +236,7 @@ def test_attention_is_deterministic_under_load(hip):
 
 
 @pytest.mark.parametrize("hm", [False, True])
-@pytest.mark.parametrize("split", [(3, 3), (1, 1)])
+@pytest.mark.parametrize("split", [(3, 3), (3, 1), (1, 1)])
 @pytest.mark.parametrize("G", [20, 64])
 def test_attention_window_relpos(hip, G, split, hm):
     ws, Bn, Hh, hd = 14, 2, 2, 80
@@ -263,6 +263,7 @@ def test_attention_window_relpos(hip, G, split, hm):
     o = o.reshape(Bn * nw * nw, Hh, ws * ws, hd).permute(0, 2, 1, 3).reshape(Bn, nw, nw, ws, ws, D)
     o = o.permute(0, 1, 3, 2, 4, 5).reshape(Bn, Gp, Gp, D)[:, :G, :G].reshape(Bn * S, D)
     assert relerr(out.float(), o) < (5e-6 if split == (3, 3) else 5e-3)
+    assert not torch.isnan(out.t).any()                      # every row of the output was written
 
 
 def test_small_attention(hip):

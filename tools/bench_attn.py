@@ -1,6 +1,7 @@
 """Attention micro-benchmark at the cascade's shapes (B = 8)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CVLM_GEMM_VARIANT_LIVE"] = "1"
 from camouflaged_vlm_amd import hip
 hip.load()
 split = (3, 3) if len(sys.argv) < 2 else tuple(int(c) for c in sys.argv[1])
