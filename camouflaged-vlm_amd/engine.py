@@ -804,7 +804,24 @@ class Cascade(_Base):
         hip.bilinear(mask_logits, B, self.g.inp_size, self.g.inp_size, alpha, R, R, sigmoid_in=True)
         return self.clip.forward(clip_image, alpha)
 
-    def cascade(self, inp, clip_image, clip_mask):
+    def cascade(self, inp, clip_image, clip_mask, pipelined: bool = False):
+        """Stage 1 + stage 2.  With the side stream enabled, stage 2 (CLIP pass 2: 1.2-round GEMM grids) runs there.
+        pipelined=False: the current stream waits for it before returning (plain stream semantics for the caller).
+        pipelined=True: it does not -- the caller's next batch starts its SAM encoder underneath this batch's stage 2
+        (a serving loop: results are complete after `torch.cuda.synchronize()` / once the side stream has been waited
+        for; the next `cascade()` call orders itself behind it)."""
         masks = self.infer_test(inp, clip_image, clip_mask)
-        _, _, pred, logits = self.stage2(masks, clip_image)
+        if not self.overlap_clip:
+            _, _, pred, logits = self.stage2(masks, clip_image)
+            return masks, pred, logits
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            _, _, pred, logits = self.stage2(masks, clip_image)
+        for t in (masks, clip_image):
+            t.record_stream(self._side)
+        for t in (pred, logits):
+            t.record_stream(main)
+        if not pipelined:
+            main.wait_stream(self._side)
         return masks, pred, logits
