@@ -14,6 +14,7 @@ from __future__ import annotations
 
 from typing import Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -62,7 +63,19 @@ class CustomCLIP(nn.Module):
                  eot_test: Optional[Sequence[int]] = None, seed: int = 0):
         super().__init__()
         if geometry is None:
-            geometry = geometry_from_cfg(cfg, len(classnames), len(classnames_test))
+            if clip_model is not None and not hasattr(clip_model, "state_dict"):
+                # an OpenAI state_dict decides the architecture, as build_model does (alpha_clip_rw/model.py:825-853)
+                a = host.clip_geometry_from_openai_state_dict(dict(clip_model))
+                size = cfg.INPUT.SIZE[0]
+                assert size == a["image_resolution"], f"cfg_imsize ({size}) must equal to clip_imsize ({a['image_resolution']})"
+                assert cfg.TRAINER.MAPLE.PROMPT_DEPTH >= 1, "For MaPLe, PROMPT_DEPTH should be >= 1"
+                geometry = spec.ClipGeometry(n_ctx=cfg.TRAINER.MAPLE.N_CTX, prompt_depth=cfg.TRAINER.MAPLE.PROMPT_DEPTH,
+                                             n_cls_train=len(classnames), n_cls_test=len(classnames_test),
+                                             **{k: a[k] for k in ("image_resolution", "patch_size", "vision_width",
+                                                                  "vision_layers", "embed_dim", "context_length",
+                                                                  "text_width", "text_layers")})
+            else:
+                geometry = geometry_from_cfg(cfg, len(classnames), len(classnames_test))
         self.geometry = geometry
         self.classnames, self.classnames_test = classnames, classnames_test
         self.eot = {"train": list(eot_train) if eot_train is not None else None,
@@ -86,17 +99,26 @@ class CustomCLIP(nn.Module):
         module._engine_text_dirty = True
 
     # ---- weights -------------------------------------------------------------------------------
-    def _load_from_clip(self, clip_model) -> None:
-        """Copy weights from a CLIP state_dict / module using OpenAI key names (visual.*, transformer.*,
-        alpha_clip_rw/model.py:864-881 renames).  Token prefix/suffix buffers need the token embedding
-        table and tokenised prompts and are left to load_state_dict."""
-        sd = clip_model.state_dict() if hasattr(clip_model, "state_dict") else dict(clip_model)
+    def _load_from_clip(self, clip_model, tokens_train=None, tokens_test=None) -> None:
+        """Weights from a CLIP module or state_dict: OpenAI names (a JIT archive's / `clip.load`'s state_dict) or the
+        reference module's names.  Restates what the reference does at construction time:
+          * alpha_clip_rw/model.py:860-881: `in_proj_weight -> in_proj.weight` on the vision tower, zero `conv1_alpha`
+            when the archive has none;
+          * cocotrainers/mapleAlphaCLIP.py:229-238: the towers land under `image_encoder.` / `text_encoder.`,
+            `logit_scale` at the top;
+          * :132-168: the fixed prompt vectors `token_prefix/suffix(_test)` = rows of the token-embedding table at the
+            tokenised "a photo of a <class>." prompts (the table itself is not part of the module's state_dict)."""
+        from_archive = not hasattr(clip_model, "state_dict")
+        sd = dict(clip_model) if from_archive else clip_model.state_dict()
+        sd = host.convert_openai_clip_state_dict(sd)
+        if from_archive:
+            sd = host.openai_fp16_roundtrip(sd)               # what build_model + .float() leave in the reference's module
         own = dict(self.named_parameters())
         own.update(dict(self.named_buffers()))
+        loaded = set()
         for k, v in sd.items():
             if k.startswith("visual."):
-                nk = "image_encoder." + k[len("visual."):].replace("in_proj_weight", "in_proj.weight").replace(
-                    "in_proj_bias", "in_proj.bias")
+                nk = "image_encoder." + k[len("visual."):]
             elif k.startswith("transformer.") or k in ("positional_embedding", "text_projection") or k.startswith("ln_final."):
                 nk = "text_encoder." + k
             elif k == "logit_scale":
@@ -105,8 +127,28 @@ class CustomCLIP(nn.Module):
                 continue
             if nk not in own:
                 continue
-            if tuple(own[nk].shape) == tuple(v.shape) or (own[nk].numel() == 1 and v.numel() == 1):
-                own[nk].data.copy_(v.detach().float().reshape(own[nk].shape))
+            if tuple(own[nk].shape) != tuple(v.shape) and not (own[nk].numel() == 1 and v.numel() == 1):
+                raise RuntimeError(f"size mismatch for {nk}: archive {tuple(v.shape)}, model {tuple(own[nk].shape)}")
+            own[nk].data.copy_(v.detach().float().reshape(own[nk].shape))
+            loaded.add(nk)
+        if "token_embedding.weight" in sd:
+            table = sd["token_embedding.weight"].detach().float()
+            n_ctx = self.geometry.n_ctx
+            for split, names, toks, sfx in (("train", self.classnames, tokens_train, ""),
+                                            ("test", self.classnames_test, tokens_test, "_test")):
+                if toks is None:
+                    if names is None:
+                        continue
+                    toks = host.tokens_for_classes(names)
+                toks = torch.as_tensor(np.asarray(toks)).long()
+                emb = table[toks]                                            # (n_cls, 77, width)
+                own["prompt_learner.token_prefix" + sfx].data.copy_(emb[:, :1])
+                own["prompt_learner.token_suffix" + sfx].data.copy_(emb[:, 1 + n_ctx:])
+                self.eot[split] = toks.argmax(-1).tolist()                   # EOT column (mapleAlphaCLIP.py:76)
+                loaded.update({"prompt_learner.token_prefix" + sfx, "prompt_learner.token_suffix" + sfx})
+        self._engine = None
+        self._engine_text_dirty = True
+        self.loaded_from_clip = sorted(loaded)
 
     def load_text_features(self, train_text_features, test_text_features):
         self.train_text_features = train_text_features
@@ -157,12 +199,17 @@ class CustomCLIP(nn.Module):
 
 
 class TestMaPLeAlphaCLIP(nn.Module):
-    """cocotrainers/mapleAlphaCLIP.py:478-494.  The reference downloads OpenAI weights here; this
-    build has no network, so weights start from the deterministic synthetic generator and are
-    expected to arrive through ``load_state_dict`` (demo.py:88-89) or ``clip_state_dict``."""
+    """cocotrainers/mapleAlphaCLIP.py:478-494.  The reference downloads the OpenAI archive here (:28-32); this build has
+    no network: pass the archive's state_dict (or the path of a file holding it: a `torch.save`d state_dict or a
+    TorchScript archive) as `clip_state_dict`, or let the weights arrive through `load_state_dict` (demo.py:88-89)."""
 
     def __init__(self, cfg, classnames_train, classnames_test, clip_state_dict=None):
         super().__init__()
         self.classnames_train = classnames_train
         self.classnames_test = classnames_test
+        if isinstance(clip_state_dict, (str, bytes)):
+            try:                                            # JIT archive first, as load_clip_to_cpu does (:34-42)
+                clip_state_dict = torch.jit.load(clip_state_dict, map_location="cpu").eval().state_dict()
+            except RuntimeError:
+                clip_state_dict = host.load_checkpoint_state_dict(clip_state_dict)
         self.model = CustomCLIP(cfg, classnames_train, classnames_test, clip_state_dict)

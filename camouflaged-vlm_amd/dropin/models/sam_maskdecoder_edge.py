@@ -51,8 +51,7 @@ class SAM(nn.Module):
         self.clip_model.to(self.device)
         self.clip_model.load_text_features(self.train_text_features, self.test_text_features)
         if MaPLeAlphaCLIP_checkpoint is not None:
-            ckpt = torch.load(MaPLeAlphaCLIP_checkpoint, map_location="cpu", weights_only=False)
-            state_dict = ckpt["state_dict"]
+            state_dict = dict(host.load_checkpoint_state_dict(MaPLeAlphaCLIP_checkpoint))   # Dassl: {"state_dict": ...}
             for k in ("prompt_learner.token_prefix", "prompt_learner.token_suffix"):
                 state_dict.pop(k, None)                     # fixed token vectors are ignored (:196-199)
             self.clip_model.load_state_dict(state_dict, strict=False)

@@ -124,3 +124,37 @@ def apply_outliers(sd: Dict[str, np.ndarray], prefix: str = "image_encoder.") ->
         out[f"{prefix}blocks.{blk}.mlp.lin1.weight"][row] *= f
         out[f"{prefix}blocks.{blk}.mlp.lin1.bias"][row] *= f
     return out
+
+
+def make_openai_clip_state_dict(c: ClipGeometry, seed: int = 0, vocab_size: int = 49408) -> Dict[str, np.ndarray]:
+    """The synthetic CLIP weights under OpenAI's key names, the way a JIT archive's state_dict carries them
+    (alpha_clip_rw/model.py:825-884 reads this layout): `visual.*` with packed `attn.in_proj_weight/bias`, bare
+    `transformer.*` / `positional_embedding` / `text_projection` / `ln_final.*` for the text tower, `token_embedding.weight`,
+    the three metadata entries -- and NO `visual.conv1_alpha.weight` (Alpha-CLIP adds it, zero-initialised)."""
+    from .spec import clip_entries
+    own = make_state_dict([e for e in clip_entries(c, prefix="") if not e[0].startswith("prompt_learner.")], seed)
+    out: Dict[str, np.ndarray] = {}
+    for k, v in own.items():
+        if k == "image_encoder.conv1_alpha.weight":
+            continue
+        if k.startswith("image_encoder."):
+            k = "visual." + k[len("image_encoder."):].replace("attn.in_proj.weight", "attn.in_proj_weight").replace(
+                "attn.in_proj.bias", "attn.in_proj_bias")
+        elif k.startswith("text_encoder."):
+            k = k[len("text_encoder."):]
+        out[k] = v
+    out["token_embedding.weight"] = make_tensor("openai.token_embedding.weight", (vocab_size, c.text_width), "embed", seed)
+    out["input_resolution"] = np.asarray(c.image_resolution, np.int64)
+    out["context_length"] = np.asarray(c.context_length, np.int64)
+    out["vocab_size"] = np.asarray(vocab_size, np.int64)
+    return out
+
+
+def n3_rest_state_dict(g: SamGeometry, c: ClipGeometry, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Everything of the full synthetic state_dict that does NOT come from the CLIP archive: the SAM side and the MaPLe
+    prompt learner's learnable tensors (ctx, proj, compound prompts and their projections).  Loaded with strict=False
+    on top of an archive-initialised model (N3 test, tools/make_golden.py --only-n3)."""
+    sd = make_full_state_dict(g, c, seed)
+    drop = ("clip_model.image_encoder.", "clip_model.text_encoder.", "clip_model.logit_scale",
+            "clip_model.prompt_learner.token_")
+    return {k: v for k, v in sd.items() if not k.startswith(drop)}

@@ -245,9 +245,9 @@ def test_openai_clip_key_mapping():
         "text_projection": torch.full((T, c.embed_dim), 6.0),
         "ln_final.weight": torch.full((T,), 7.0),
         "logit_scale": torch.tensor(4.6052),
-        "token_embedding.weight": torch.zeros(10, T),                 # not part of the drop-in's state_dict
-        "visual.positional_embedding": torch.zeros(3, W),             # wrong shape: must be ignored, not crash
     }
+    with pytest.raises(RuntimeError, match="size mismatch"):          # load_state_dict(strict=False) still rejects shapes
+        CustomCLIP(geometry=c, clip_model=dict(fake, **{"visual.positional_embedding": torch.zeros(3, W)}))
     m = CustomCLIP(geometry=c, clip_model=fake)
     sd = m.state_dict()
     assert float(sd["image_encoder.conv1.weight"].mean()) == 0.5
@@ -259,7 +259,7 @@ def test_openai_clip_key_mapping():
     assert float(sd["text_encoder.positional_embedding"].mean()) == 5.0
     assert float(sd["text_encoder.text_projection"].mean()) == 6.0 and float(sd["text_encoder.ln_final.weight"].mean()) == 7.0
     assert abs(float(sd["logit_scale"]) - 4.6052) < 1e-6
-    assert float(sd["image_encoder.conv1_alpha.weight"].abs().max()) > 0      # untouched synthetic init
+    assert float(sd["image_encoder.conv1_alpha.weight"].abs().max()) == 0     # archive without it: zero-initialised (:877-881)
 
 
 def test_partial_checkpoint_loads_non_strict():
@@ -275,3 +275,105 @@ def test_partial_checkpoint_loads_non_strict():
     res = m.load_state_dict(part, strict=False)
     assert "unknown.key" in res.unexpected_keys and len(res.missing_keys) > 100
     assert float(m.state_dict()["image_encoder.patch_embed.proj.bias"].mean()) == 9.0
+
+
+# ---- N3: real-checkpoint formats -------------------------------------------------------------------------------------
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _maple_cfg(c):
+    return _NS(MODEL=_NS(BACKBONE=_NS(NAME="ViT-L/14@336px")),
+               TRAINER=_NS(MAPLE=_NS(N_CTX=c.n_ctx, CTX_INIT="a photo of a", PREC="fp32", PROMPT_DEPTH=c.prompt_depth)),
+               INPUT=_NS(SIZE=[c.image_resolution, c.image_resolution]))
+
+
+def build_from_openai_archive(device=None):
+    """The dropin driven the way the reference is: archive state_dict -> TestMaPLeAlphaCLIP -> models.make ->
+    load_mapleAlphaCLIP -> strict=False load of everything the archive does not hold."""
+    from camouflaged_vlm_amd import host
+    if cv.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, cv.DROPIN_DIR)
+    import models
+    from cocotrainers.mapleAlphaCLIP import TestMaPLeAlphaCLIP
+    g, c = spec.TINY_SAM, spec.TINY_CLIP
+    names = host.ovcamo_constants()
+    tr, te = names["names_train"].tolist()[:c.n_cls_train], names["names_test"].tolist()[:c.n_cls_test]
+    osd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.make_openai_clip_state_dict(c).items()}
+    clip = TestMaPLeAlphaCLIP(_maple_cfg(c), tr, te, clip_state_dict=osd).model
+    enc = dict(name="sam", img_size=g.inp_size, mlp_ratio=4, patch_size=16, qkv_bias=True, use_rel_pos=True,
+               window_size=14, out_chans=256, prompt_embed_dim=256, embed_dim=g.embed_dim, depth=g.depth,
+               num_heads=g.num_heads, global_attn_indexes=list(g.global_attn_indexes))
+    model = models.make({"name": "sam_maskdecoder_edge", "args": {"inp_size": g.inp_size, "loss": "iou", "encoder_mode": enc}})
+    if device is not None:
+        model = model.to(device)
+    model.train_text_features = model.train_text_features[:c.n_cls_train]
+    model.test_text_features = model.test_text_features[:c.n_cls_test]
+    model.load_mapleAlphaCLIP(clip)
+    res = model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.n3_rest_state_dict(g, c).items()}, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("clip_model.") for k in res.missing_keys)
+    return model.eval(), clip
+
+
+def test_openai_archive_loads_like_the_reference(golden_dir=os.path.join(REPO, "tests", "golden")):
+    """N3: an OpenAI-named CLIP state_dict (packed in_proj_weight, no conv1_alpha, token_embedding table, metadata keys)
+    through the dropin == the same archive through the REFERENCE's build_model + CustomCLIP (tools/make_golden.py
+    --only-n3): every one of the 99 CLIP tensors by checksum, the four token buffers element-wise, the EOT columns."""
+    with np.load(os.path.join(golden_dir, "n3_openai_load.npz")) as z:
+        gd = {k: z[k] for k in z.files}
+    model, clip = build_from_openai_archive()
+    sd = clip.state_dict()
+    assert sorted(sd.keys()) == gd["keys"].tolist()
+    for k, (s1, s2) in zip(gd["keys"].tolist(), gd["sums"]):
+        t = sd[k].double()
+        assert abs(float(t.sum()) - s1) <= 1e-9 * max(1.0, abs(s1)) and abs(float(t.pow(2).sum()) - s2) <= 1e-9 * max(1.0, s2), k
+    pl = "prompt_learner."
+    for name in ("token_prefix", "token_suffix", "token_prefix_test", "token_suffix_test"):
+        assert np.array_equal(sd[pl + name].numpy(), gd[name]), name
+    assert float(sd["image_encoder.conv1_alpha.weight"].abs().max()) == 0.0        # zero-initialised alpha branch
+    assert clip._eot("test") == gd["eot_test"].tolist() and clip._eot("train") == gd["eot_train"].tolist()
+    # the matrix tensors carry fp16-rounded values (convert_weights), the others do not
+    w = sd["image_encoder.transformer.resblocks.0.attn.in_proj.weight"]
+    assert torch.equal(w, w.half().float())
+    ln = sd["image_encoder.ln_pre.weight"]
+    assert not torch.equal(ln, ln.half().float())
+
+
+def test_openai_geometry_inference_and_renames():
+    from camouflaged_vlm_amd import host
+    c = spec.TINY_CLIP
+    osd = synth.make_openai_clip_state_dict(c)
+    a = host.clip_geometry_from_openai_state_dict(osd)
+    assert (a["image_resolution"], a["patch_size"], a["vision_width"], a["vision_layers"]) == \
+           (c.image_resolution, c.patch_size, c.vision_width, c.vision_layers)
+    assert (a["embed_dim"], a["context_length"], a["text_width"], a["text_heads"], a["text_layers"], a["vocab_size"]) == \
+           (c.embed_dim, c.context_length, c.text_width, c.text_heads, c.text_layers, 49408)
+    conv = host.convert_openai_clip_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in osd.items()})
+    assert "input_resolution" not in conv and "visual.transformer.resblocks.0.attn.in_proj.weight" in conv
+    assert "transformer.resblocks.0.attn.in_proj_weight" in conv                 # the text tower keeps nn.MultiheadAttention names
+    assert torch.equal(conv["visual.transformer.resblocks.0.attn.in_proj.weight"],
+                       torch.from_numpy(osd["visual.transformer.resblocks.0.attn.in_proj_weight"]))   # element-wise, untouched
+    assert tuple(conv["visual.conv1_alpha.weight"].shape) == (c.vision_width, 1, c.patch_size, c.patch_size)
+    with pytest.raises(NotImplementedError):
+        host.clip_geometry_from_openai_state_dict({"visual.layer1.0.conv1.weight": torch.zeros(1)})
+
+
+def test_dassl_checkpoint_drops_the_fixed_token_vectors(tmp_path):
+    """models/sam_maskdecoder_edge.py:192-201: a Dassl `model-best.pth.tar` ({"state_dict": ..., "epoch": ...}) updates the
+    prompt learner but never `token_prefix` / `token_suffix`; the `_test` vectors and everything else in it do load."""
+    model, clip = build_from_openai_archive()
+    before = {k: v.clone() for k, v in clip.state_dict().items()}
+    ck = {"prompt_learner.ctx": torch.full_like(before["prompt_learner.ctx"], 0.25),
+          "prompt_learner.token_prefix": torch.full_like(before["prompt_learner.token_prefix"], 7.0),
+          "prompt_learner.token_suffix": torch.full_like(before["prompt_learner.token_suffix"], 7.0),
+          "prompt_learner.token_prefix_test": torch.full_like(before["prompt_learner.token_prefix_test"], 3.0)}
+    path = str(tmp_path / "model-best.pth.tar")
+    torch.save({"state_dict": ck, "epoch": 5, "val_result": 0.0}, path)
+    model.load_mapleAlphaCLIP(clip, path)
+    after = clip.state_dict()
+    assert torch.equal(after["prompt_learner.token_prefix"], before["prompt_learner.token_prefix"])
+    assert torch.equal(after["prompt_learner.token_suffix"], before["prompt_learner.token_suffix"])
+    assert float(after["prompt_learner.ctx"].mean()) == 0.25 and float(after["prompt_learner.token_prefix_test"].mean()) == 3.0
+    assert torch.equal(after["image_encoder.proj"], before["image_encoder.proj"])
+    assert clip._engine is None and clip._engine_text_dirty

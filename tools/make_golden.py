@@ -290,6 +290,61 @@ def hires_digest(out_dir, mods):
     print("hires1536: encoder output %s in %.1f s; std %.4f min %.3f max %.3f" % (out.shape, dt, out.std(), out.min(), out.max()))
 
 
+def n3_openai(out_dir, mods):
+    """N3: the reference's own loading path -- build_model(OpenAI-named state_dict) -> CustomCLIP (token vectors from the
+    embedding table and the tokenizer) -> load_mapleAlphaCLIP -> strict=False load of the rest -- on a synthetic archive
+    (synth.make_openai_clip_state_dict).  Saved: per-key checksums of the resulting CustomCLIP state_dict, the token
+    buffers, and the cascade's outputs on two images."""
+    mm, ml, cm, train_names, test_names = mods
+    g, c = spec.TINY_SAM, spec.TINY_CLIP
+    osd = synth.make_openai_clip_state_dict(c)
+    clip = cm.build_model({k: torch.from_numpy(np.asarray(v)) for k, v in osd.items()},
+                          design_details={"trainer": "MaPLe", "vision_depth": 0, "language_depth": 0, "vision_ctx": 0,
+                                          "language_ctx": 0, "maple_length": c.n_ctx}).float()
+    cfg = DotDict({"MODEL": {"BACKBONE": {"NAME": "ViT-L/14@336px"}},
+                   "TRAINER": {"MAPLE": {"N_CTX": c.n_ctx, "CTX_INIT": "a photo of a", "PREC": "fp32",
+                                         "PROMPT_DEPTH": c.prompt_depth}},
+                   "INPUT": {"SIZE": [c.image_resolution, c.image_resolution]}})
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        custom = ml.CustomCLIP(cfg, train_names[:c.n_cls_train], test_names[:c.n_cls_test], clip)
+        enc = dict(name="sam", img_size=g.inp_size, mlp_ratio=g.mlp_ratio, patch_size=g.patch_size,
+                   qkv_bias=True, use_rel_pos=True, window_size=g.window_size, out_chans=g.out_chans,
+                   scale_factor=32, input_type="fft", freq_nums=0.25, prompt_type="highpass",
+                   prompt_embed_dim=g.prompt_embed_dim, tuning_stage=1234, handcrafted_tune=True,
+                   embedding_tune=True, adaptor="adaptor", embed_dim=g.embed_dim, depth=g.depth,
+                   num_heads=g.num_heads, global_attn_indexes=list(g.global_attn_indexes))
+        model = mm.make({"name": "sam_maskdecoder_edge", "args": {"inp_size": g.inp_size, "loss": "iou", "encoder_mode": enc}})
+        model.device = torch.device("cpu")
+        model.train_text_features = model.train_text_features[:c.n_cls_train].float()
+        model.test_text_features = model.test_text_features[:c.n_cls_test].float()
+        model.load_mapleAlphaCLIP(custom)
+    finally:
+        os.chdir(cwd)
+    rest = {k: torch.from_numpy(v) for k, v in synth.n3_rest_state_dict(g, c).items()}
+    missing, unexpected = model.load_state_dict(rest, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("clip_model.") for k in missing), missing[:5]
+    model.eval()
+    inp, clip_image, clip_mask = synth.make_inputs(g, c, batch=2)
+    masks, preds, logits, logits1 = run_reference(model, inp, clip_image, clip_mask, c.image_resolution)
+    csd = custom.state_dict()
+    keys = sorted(csd.keys())
+    sums = np.array([[float(csd[k].double().sum()), float(csd[k].double().pow(2).sum())] for k in keys], np.float64)
+    pl = "prompt_learner."
+    np.savez_compressed(
+        os.path.join(out_dir, "n3_openai_load.npz"), keys=np.array(keys), sums=sums,
+        token_prefix=csd[pl + "token_prefix"].numpy(), token_suffix=csd[pl + "token_suffix"].numpy(),
+        token_prefix_test=csd[pl + "token_prefix_test"].numpy(), token_suffix_test=csd[pl + "token_suffix_test"].numpy(),
+        eot_test=custom.tokenized_prompts_test.argmax(dim=-1).numpy().astype(np.int32),
+        eot_train=custom.tokenized_prompts.argmax(dim=-1).numpy().astype(np.int32),
+        bank_test=model.test_text_features.numpy(), mask_logits=masks.astype(np.float32), pred=preds.astype(np.int64),
+        class_logits=logits.astype(np.float32), pass1_logits=logits1.astype(np.float32))
+    print("n3: %d CLIP keys; mask std %.3f; pred %s; conv1_alpha |max| %.1e" %
+          (len(keys), masks.std(), preds, float(csd["image_encoder.conv1_alpha.weight"].abs().max())))
+
+
 def sam_plain(out_dir, mods):
     """Registry entry ``sam`` (models/sam.py:298-440): encoder + vanilla MaskDecoder, no prompts -> `infer` masks."""
     import importlib
@@ -333,6 +388,7 @@ if __name__ == "__main__":
     ap.add_argument("--only-sam-plain", action="store_true")
     ap.add_argument("--only-outliers", action="store_true")
     ap.add_argument("--only-hires-digest", action="store_true")
+    ap.add_argument("--only-n3", action="store_true")
     ap.add_argument("--skip-tiny", action="store_true")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -342,6 +398,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if args.only_outliers:
         tiny_outliers(args.out, mods)
+        sys.exit(0)
+    if args.only_n3:
+        n3_openai(args.out, mods)
         sys.exit(0)
     if args.only_hires_digest:
         hires_digest(args.out, mods)
