@@ -15,6 +15,8 @@
 //     1.13 us against 0.79 us for its 33 MFMAs alone (probe builds, tools/trace_attn_g64.py).
 //   * K and V tiles (32 keys) arrive by LDS-DMA into two three-slot rings, K running one tile ahead of V; they are
 //     issued three (K) / two (V) tiles before their first use and retired with counted vmcnt, never drained.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "../../include/cvlm.h"
 
@@ -390,6 +392,361 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
     }
 }
 
+// =====================================================================================================================
+// 64 x 64 map, TWO key tiles (= one key row of the map, 64 keys) per phase.
+// Why (tools/trace_attn_g64.py, probe build): in the kernel above a wave's softmax phase X takes 0.96 us per 32-key tile
+// for ~90 VALU instructions -- it is latency-bound (one wave per SIMD is in X at a time, nothing hides its dependency
+// chains): a probe that ran a second, independent softmax of the same size inside X made the phase only 10-23 % longer.
+// So the phase is given twice the work: X normalises 64 keys at once (one running-max update, one rescale), Y runs
+// 66 MFMAs back to back (P.V of both tiles, then the scores of the next two).  Half the phases and barriers per key.
+// Rings: four K and four V slots (two pairs each); a carrier refills the pair that was read in the previous round, the
+// batch has two phases to land and is retired with vmcnt(0) (no younger batch is in flight at that point).
+__global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
+                                                              const half_t* __restrict__ vt_lo) {
+    constexpr int L = 64, HD = 80, KS = 5, ND = 3, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, NPAIR = NTILE / 2;
+    constexpr int VROWS = 96, VROW_B = KT * 2;
+    constexpr int KPL_B = KT * KP * 2, VPL_B = VROWS * VROW_B;
+    constexpr int KSLOT_B = 2 * KPL_B, VSLOT_B = 2 * VPL_B, NSLOT = 4;
+    constexpr int KPL = KPL_B / 2;
+    constexpr int DPW = 3;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Kring = smem;
+    unsigned char* Vring = smem + NSLOT * KSLOT_B;
+    float* T = (float*)(Vring + NSLOT * VSLOT_B);                    // [256][LTP]  (Tw first, then Th)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* const trace = g_g64_trace;
+    const unsigned long long tr_start = trace ? wall_clock64() : 0;
+    const unsigned long long tk_start = trace ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long tr_x = 0, tr_xb = 0, tr_y = 0, tr_yb = 0, tr_pro = 0;
+    const bool grpB = wave >= 4;
+    const int qc = lane & 31, half = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int D = g.heads * HD;
+    const half_t* qkv_hi = (const half_t*)g.qkv_hi;
+    const half_t* qkv_lo = (const half_t*)g.qkv_lo;
+    const QkvStrides QS = qkv_strides(g.qkv_layout, S, g.B, g.heads, HD);
+
+    // ---- DMA plan (as above): waves 0..3 carry K, waves 4..7 carry V^T; running source pointers
+    const half_t* dsrc[DPW];
+    int ddst[DPW];
+    bool dok[DPW];
+    int64_t tile_stride;
+    if (!grpB) {
+        tile_stride = (int64_t)KT * QS.st;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int i = wave * DPW + j;
+            const int pl = i / 6, sub = i - pl * 6;
+            const int c = sub * 64 + lane;
+            int row = c / 11, ch = c - row * 11;
+            dok[j] = row < KT;
+            if (row >= KT) row = KT - 1;
+            if (ch >= 10) ch = 0;
+            dsrc[j] = (pl ? qkv_lo : qkv_hi) + qkv_offset(QS, b, row, 1, head) + ch * 8;
+            ddst[j] = pl * KPL_B + sub * 1024;
+        }
+    } else {
+        tile_stride = KT;
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            const int i = (wave - 4) * DPW + j;
+            const int pl = i / 6, sub = i - pl * 6;
+            const int row = sub * 16 + (lane >> 2), pos = lane & 3;
+            const int chunk = pos ^ ((row >> 2) & 3);
+            const int drow = row < HD ? row : HD - 1;
+            dok[j] = true;
+            dsrc[j] = (pl ? vt_lo : vt_hi) + (((int64_t)b * g.heads + head) * HD + drow) * S + chunk * 8;
+            ddst[j] = pl * VPL_B + sub * 1024;
+        }
+    }
+    auto issue_next = [&](int slot) {                                // this wave's share of the next K or V tile
+        unsigned char* base = (grpB ? Vring + slot * VSLOT_B : Kring + slot * KSLOT_B);
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            if (dok[j]) glds16(dsrc[j], base + ddst[j]);
+            dsrc[j] += tile_stride;
+        }
+    };
+    // prologue DMA: K pairs 0 and 1 by waves 0..3, V pair 0 by waves 4..7 (they land under the table build below)
+    issue_next(0);
+    issue_next(1);
+    if (!grpB) { issue_next(2); issue_next(3); }
+
+    // ---- queries, rel-pos tables (as above)
+    const int qslot = blockIdx.x * 256 + wave * 32 + qc;
+    half8 qh[KS], ql[KS];
+    {
+        const int64_t qo = qkv_offset(QS, b, qslot, 0, head);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qh[ks] = *(const half8*)(qkv_hi + qo + 16 * ks + 8 * half);
+            ql[ks] = *(const half8*)(qkv_lo + qo + 16 * ks + 8 * half);
+        }
+    }
+    const int qhh = qslot / L, qww = qslot - qhh * L;
+    float* Tq = T + (wave * 32 + qc) * LTP;
+    auto build_table = [&](const half_t* Rhi, const half_t* Rlo, int cq) {   // T[q][k] = (Q . R^T)[q][cq - k + L - 1]
+#pragma unroll 1
+        for (int st = 0; st < (2 * L - 1 + 31) / 32; ++st) {
+            floatx16 u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = 0.f;
+            int rr = st * 32 + qc;
+            rr = rr < 2 * L - 1 ? rr : 2 * L - 2;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 ah = *(const half8*)(Rhi + rr * HD + 16 * ks + 8 * half);
+                const half8 al = *(const half8*)(Rlo + rr * HD + 16 * ks + 8 * half);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], u, 0, 0, 0);
+                u = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], u, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int kidx = cq + (L - 1) - j;
+                if (j < 2 * L - 1 && kidx >= 0 && kidx < L) Tq[kidx] = u[r];
+            }
+        }
+    };
+    f32x2 twr[2][8];                                                 // Tw[q][32*pz + (r&3) + 8*(r>>2) + 4*half], r = 2i, 2i+1
+    build_table((const half_t*)g.relw_hi, (const half_t*)g.relw_lo, qww);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r0 = 2 * i, r1 = 2 * i + 1;
+            twr[pz][i] = f32x2{Tq[32 * pz + (r0 & 3) + 8 * (r0 >> 2) + 4 * half], Tq[32 * pz + (r1 & 3) + 8 * (r1 >> 2) + 4 * half]};
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // each lane re-reads only the row it wrote
+    build_table((const half_t*)g.relh_hi, (const half_t*)g.relh_lo, qhh);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            half_t hh, ll;
+            split_h2(((float)qh[ks][j] + (float)ql[ks][j]) * g.scale, hh, ll);
+            qh[ks][j] = hh; ql[ks][j] = ll;
+        }
+
+    // ---- state
+    float m_run = -INFINITY, l_run = 0.f;
+    floatx16 o[ND], s[2];
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+    half8 ph[2][2] = {}, pl[2][2] = {};                              // [tile of the pair][16-key step]
+    const int v_pos[2] = {((0 + half) ^ ((qc >> 2) & 3)) * 16, ((2 + half) ^ ((qc >> 2) & 3)) * 16};
+    const int k_lane_off = qc * KP + 8 * half;
+
+    auto QK2 = [&](int kslot0) {                                     // scores of the pair in slots kslot0, kslot0 + 1
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const half_t* kr = (const half_t*)(Kring + (kslot0 + e) * KSLOT_B) + k_lane_off;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[e][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 kh = *(const half8*)(kr + 16 * ks);
+                const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
+                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[e], 0, 0, 0);
+                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[e], 0, 0, 0);
+                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[e], 0, 0, 0);
+            }
+        }
+    };
+    // Y(q): O^T += V^T.P^T for both tiles of pair q (12 fragment groups), then the scores of pair q + 1 (10 k-steps), as
+    // ONE stream of 22 stages; the LDS fragments of stage i + PD are requested before the three MFMAs of stage i.
+    auto Y = [&](int vslot0, int kslot0) {
+        // Fragment reads are inline asm with immediate offsets and COUNTED waits: left to hipcc, the stream got an
+        // `s_waitcnt lgkmcnt(0)` every third stage, i.e. the full LDS latency (reads of three stages ahead included) was
+        // exposed seven times per phase: 1.9 us for 66 MFMAs that take 1.15 us.  LDS returns in order, so "all but the
+        // 2 * PD youngest reads" is exactly "stage I's two fragments have arrived".
+        const unsigned vb = (unsigned)(size_t)(LDS_AS const unsigned char*)(Vring + vslot0 * VSLOT_B + qc * VROW_B);
+        unsigned va[2] = {vb + (unsigned)v_pos[0], vb + (unsigned)v_pos[1]};
+        unsigned ka = (unsigned)(size_t)(LDS_AS const unsigned char*)(Kring + kslot0 * KSLOT_B) + 2u * (unsigned)k_lane_off;
+        constexpr int PD = CVLM_G64_PD, RS = PD + 1, NST = 22;
+        half8 fa[RS], fb[RS];
+        auto load = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            const unsigned a_v0 = va[0], a_v1 = va[1], a_k = ka;     // named outside the `if constexpr` so that the lambda captures them
+            if constexpr (I < 12) {
+                constexpr int e = I / 6, k2 = (I % 6) / 3, n = I % 3;
+                constexpr int off = e * VSLOT_B + (32 * n) * VROW_B;
+                const unsigned a_v = k2 ? a_v1 : a_v0;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[I % RS]) : "v"(a_v), "n"(off));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I % RS]) : "v"(a_v), "n"(off + VPL_B));
+            } else {
+                constexpr int e = (I - 12) / 5, ks = (I - 12) % 5;
+                constexpr int off = e * KSLOT_B + 32 * ks;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[I % RS]) : "v"(a_k), "n"(off));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I % RS]) : "v"(a_k), "n"(off + KPL_B));
+            }
+        };
+        auto compute = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            const half8 a = fa[I % RS], bq = fb[I % RS];
+            if constexpr (I < 12) {
+                constexpr int e = I / 6, k2 = (I % 6) / 3, n = I % 3;
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ph[e][k2], o[n], 0, 0, 0);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, ph[e][k2], o[n], 0, 0, 0);
+                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pl[e][k2], o[n], 0, 0, 0);
+            } else {
+                constexpr int e = (I - 12) / 5, ks = (I - 12) % 5;
+                if constexpr (ks == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[e][r] = 0.f;
+                }
+                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s[e], 0, 0, 0);
+                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s[e], 0, 0, 0);
+                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s[e], 0, 0, 0);
+            }
+        };
+        load(std::integral_constant<int, 0>{});
+        if constexpr (PD >= 2) load(std::integral_constant<int, 1>{});
+        if constexpr (PD >= 3) load(std::integral_constant<int, 2>{});
+        if constexpr (PD >= 4) load(std::integral_constant<int, 3>{});
+        auto stage = [&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int ahead = (NST - 1 - I) < PD ? (NST - 1 - I) : PD;     // stages whose reads are younger than stage I's
+            if constexpr (I + PD < NST) load(std::integral_constant<int, I + PD>{});
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ahead) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef CVLM_G64_NOMFMA
+            asm volatile("" ::"v"(fa[I % RS]), "v"(fb[I % RS]));                  // probe: fragment reads only
+            if (I == NST - 1) { asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(o[0]), "+v"(o[1]), "+v"(o[2])); }
+            return;
+#endif
+            compute(ic);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{});
+        stage(std::integral_constant<int, 2>{}); stage(std::integral_constant<int, 3>{});
+        stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
+        stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{});
+        stage(std::integral_constant<int, 8>{}); stage(std::integral_constant<int, 9>{});
+        stage(std::integral_constant<int, 10>{}); stage(std::integral_constant<int, 11>{});
+        stage(std::integral_constant<int, 12>{}); stage(std::integral_constant<int, 13>{});
+        stage(std::integral_constant<int, 14>{}); stage(std::integral_constant<int, 15>{});
+        stage(std::integral_constant<int, 16>{}); stage(std::integral_constant<int, 17>{});
+        stage(std::integral_constant<int, 18>{}); stage(std::integral_constant<int, 19>{});
+        stage(std::integral_constant<int, 20>{}); stage(std::integral_constant<int, 21>{});
+    };
+    // X(q): online softmax over the 64 keys of key row q (both tiles share the row bias th; the column bias is per tile)
+    auto X = [&](float th) {
+#ifdef CVLM_G64_NOX
+        asm volatile("" : "+v"(ph[0][0]), "+v"(ph[1][1]), "+v"(pl[0][0]), "+v"(pl[1][1]));   // probe: no VALU phase
+        return;
+#endif
+        f32x2 z[2][8];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[e][i] = f32x2{s[e][2 * i], s[e][2 * i + 1]} + twr[e][i];
+        float mx0 = fmaxf(z[0][0].x, z[0][0].y), mx1 = fmaxf(z[1][0].x, z[1][0].y);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            mx0 = fmaxf(fmaxf(mx0, z[0][i].x), z[0][i].y);
+            mx1 = fmaxf(fmaxf(mx1, z[1][i].x), z[1][i].y);
+        }
+        const float mx = half_swap_max(fmaxf(mx0, mx1)) + th;
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const f32x2 c2 = f32x2{(th - m_new) * LOG2E, (th - m_new) * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
+        f32x2 acc0 = f32x2{0.f, 0.f}, acc1 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 a0 = z[0][i] * l2 + c2, a1 = z[1][i] * l2 + c2;
+            z[0][i] = f32x2{__builtin_amdgcn_exp2f(a0.x), __builtin_amdgcn_exp2f(a0.y)};
+            z[1][i] = f32x2{__builtin_amdgcn_exp2f(a1.x), __builtin_amdgcn_exp2f(a1.y)};
+            acc0 += z[0][i];
+            acc1 += z[1][i];
+        }
+        l_run = l_run * alpha + ((acc0.x + acc0.y) + (acc1.x + acc1.y));
+        if (!__all(m_new == m_run)) {
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+        }
+        m_run = m_new;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x2 v = z[e][4 * k2 + p];
+                    const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+                    const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v.x - (float)h[0], v.y - (float)h[1]));
+                    ph[e][k2][2 * p] = h[0]; ph[e][k2][2 * p + 1] = h[1];
+                    pl[e][k2][2 * p] = l[0]; pl[e][k2][2 * p + 1] = l[1];
+                }
+    };
+
+    // ---- every wave runs  QK(pair 0) | X(0) Y(0) | X(1) Y(1) | ...  with Y(q) = PV(pair q), QK(pair q+1); group B one
+    // phase behind group A.  Global phase: A runs X(q) at 2q, Y(q) at 2q + 1; B one later.
+    //   reads:  K pair q+1 and V pair q by A in phase 2q + 1, by B in phase 2q + 2; pair q lives in slots 2 (q & 1), +1
+    //   DMA:    K carriers (A) fetch K pair q+2 at the start of their Y(q) into the slots of K pair q (last read in phase
+    //           2q), wait for it at the end of their X(q+1) (phase 2q + 2): first use is their own Y(q+1) in phase 2q + 3;
+    //           V carriers (B) fetch V pair q+1 at the start of their X(q) (phase 2q + 1) into the slots of V pair q-1 (last
+    //           read in phase 2q), wait for it at the end of their Y(q) (phase 2q + 2): first use is A's Y(q+1) in 2q + 3.
+    wait_vm<0>();
+    phase_barrier();
+    if (grpB) phase_barrier();                                       // B starts one phase late
+    QK2(0);
+    phase_barrier();
+    if (trace) tr_pro = wall_clock64() - tr_start;
+#pragma unroll 1
+    for (int q = 0; q < NPAIR; ++q) {
+        const int cur = 2 * (q & 1), oth = 2 - cur;                  // slots of pair q / of pairs q - 1 and q + 1
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (trace) c0 = wall_clock64();
+        if (grpB && q + 1 < NPAIR) { issue_next(oth); issue_next(oth + 1); }
+        X(Tq[q]);
+        if (trace) { asm volatile("" ::"v"(ph[0][0]), "v"(pl[1][1])); c1 = wall_clock64(); }
+        if (!grpB) wait_vm<0>();
+        phase_barrier();
+        if (trace) c2 = wall_clock64();
+        if (!grpB && q + 2 < NPAIR) { issue_next(cur); issue_next(cur + 1); }
+        Y(cur, oth);                                                 // the last scores (pair NPAIR) are computed and dropped
+        if (trace) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][0]), "v"(o[2][0])); c3 = wall_clock64(); }
+        if (grpB) wait_vm<0>();
+        phase_barrier();
+        if (trace) { const unsigned long long c4 = wall_clock64(); tr_x += c1 - c0; tr_xb += c2 - c1; tr_y += c3 - c2; tr_yb += c4 - c3; }
+    }
+    if (!grpB) phase_barrier();                                      // match B's extra leading barrier
+
+    const float l_tot = half_swap_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    const int64_t orow = ((int64_t)b * S + qslot) * D + head * HD;
+    half_t* oh = (half_t*)g.out_hi + orow;
+    half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
+#pragma unroll
+    for (int n = 0; n < ND; ++n)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d = 32 * n + 8 * rg + 4 * half;
+            if (d < HD) {
+                half_t h[4], l4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_h2(o[n][4 * rg + j] * inv, h[j], l4[j]);
+                *(half4*)(oh + d) = half4{h[0], h[1], h[2], h[3]};
+                if (ol) *(half4*)(ol + d) = half4{l4[0], l4[1], l4[2], l4[3]};
+            }
+        }
+    if (trace && lane == 0) {
+        unsigned long long* o8 = trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+        o8[0] = tr_pro; o8[1] = tr_x; o8[2] = tr_xb; o8[3] = tr_y; o8[4] = tr_yb; o8[5] = wall_clock64() - tr_start;
+        o8[6] = __builtin_amdgcn_s_memtime() - tk_start;
+    }
+}
+
 // V [key][dim] (as the qkv GEMM leaves it) -> V^T [b][head][dim][key'], both planes; 64 keys x 80 dims per workgroup
 __global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g, half_t* __restrict__ vt_hi,
                                                           half_t* __restrict__ vt_lo) {
@@ -443,6 +800,19 @@ static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
     half_t* vt = (half_t*)g.workspace;
     hipLaunchKernelGGL(transpose_v_kernel, dim3(S / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
     CVLM_CHECK_LAUNCH();
+    if constexpr (L == 64) {
+        static const int pair = [] { const char* e = getenv("CVLM_ATTN_G64_PAIR"); return e ? atoi(e) : 1; }();
+        if (pair) {
+            constexpr int smem2 = 4 * (2 * 5632) + 4 * (2 * 6144) + 256 * (L + 1) * 4;
+            static bool attr2[16] = {};
+            if (cvlm_first_on_device(attr2))
+                (void)hipFuncSetAttribute((const void*)attn_g64pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+            hipLaunchKernelGGL(attn_g64pair_kernel, dim3(S / 256, g.heads, g.B), dim3(512), smem2, s, g, (const half_t*)vt,
+                               (const half_t*)(vt + plane));
+            CVLM_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(attn_g64pp_kernel<L>, dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
                        (const half_t*)(vt + plane));
     CVLM_CHECK_LAUNCH();

@@ -17,7 +17,10 @@ torch.cuda.synchronize()
 assert lib.cvlm_debug_set_attn_g64_trace(C.c_void_p(buf.data_ptr())) == 0
 fn(); torch.cuda.synchronize()
 assert lib.cvlm_debug_set_attn_g64_trace(None) == 0
-t = buf.cpu().numpy().reshape(-1, 8, 8) / 100.0          # [wg][wave][field] in us
+raw = buf.cpu().numpy().reshape(-1, 8, 8)
+if raw[:, :, 6].max() > 0:
+    print(f"shader clock over the kernel: {(raw[:, :, 6] / (raw[:, :, 5] / 100.0)).mean() / 1e3:.3f} GHz (s_memtime ticks / wall)")
+t = raw / 100.0          # [wg][wave][field] in us
 for grp, lab in ((slice(0, 4), "group A (waves 0-3)"), (slice(4, 8), "group B (waves 4-7)")):
     v = t[:, grp, :].reshape(-1, 8)
     print(f"{lab}: prologue {v[:,0].mean():6.1f}  X {v[:,1].mean():6.1f}  X wait+barrier {v[:,2].mean():6.1f}  "
