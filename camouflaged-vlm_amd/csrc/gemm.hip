@@ -541,7 +541,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     for (int nt = 0; nt < 4; ++nt) {
         const int n = bn + wn * 64 + nt * 16 + fq * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[nt][j] = (g.bias && n + j < g.N) ? g.bias[n + j] : 0.f;
+        for (int j = 0; j < 4; ++j) bv[nt][j] = (g.bias && !g.ln_stats && n + j < g.N) ? g.bias[n + j] : 0.f;
     }
     // ---- fast epilogue: each 16 x 64 accumulator slab goes through a per-wave LDS buffer so that global
     // stores (and the residual read) are whole 128- / 256-byte row segments, 16 bytes per lane.  The direct
@@ -552,8 +552,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         // The activation is a compile-time constant of the body: one wave-uniform switch per tile.  (A per-value
         // runtime switch compiled to ~8 scalar branches per output and a 240 KB epilogue that missed the
         // instruction cache on every slab: 19 us of a 112 us tile, profiles/r01_gemm_probes.md.)
-        auto fast_epi = [&](auto act_c) {
+        // MODE 0: plain.  MODE 1: LayerNorm folded into this GEMM (ln_stats): the staged value is alpha * acc; the row
+        // statistics, the column sums of the weight, bias and activation are applied on the way out of LDS, where a lane
+        // owns 8 consecutive columns of one row.  MODE 2: residual in h2 planes + row statistics of the result
+        // (res_hi / row_stats): the producer side of MODE 1.
+        auto fast_epi = [&](auto act_c, auto mode_c) {
             constexpr int ACT = decltype(act_c)::value;
+            constexpr int MODE = decltype(mode_c)::value;
             constexpr int EP = 68;                                    // floats per staged row (64 + 4 pad)
             constexpr int LDS_BYTES = (NSTAGE == 6 ? 1 : (NSTAGE >= 4 ? 2 : NSTAGE)) * STAGE;
             constexpr int NBUF = (LDS_BYTES >= NWAVE * 2 * 16 * EP * 4) ? 2 : 1;   // two slabs in flight when LDS allows
@@ -574,6 +579,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 hm_b = (mw + rowh) / g.hm_S;
                 hm_t = (mw + rowh) - hm_b * g.hm_S;
             }
+            float cs8[8], b8[8];                                      // MODE 1: column sums / bias of this lane's 8 columns
+            float ln_rs[MT][2], ln_c[MT][2];                          // MODE 1: rstd and mu * rstd of this lane's 2 * MT rows
+            if (MODE == 1) {
+                const float ln_inv_d = 1.0f / (float)g.ln_D;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool okc = nh + j < g.N;
+                    cs8[j] = okc ? g.ln_colsum[nh + j] : 0.f;
+                    b8[j] = (okc && g.bias) ? g.bias[nh + j] : 0.f;
+                }
+                // all row statistics of the tile up front (one batch of loads, v_rsq instead of an IEEE sqrt + divide per
+                // row piece: the first version spent ~7 us per 256^2 tile here, as much as the LayerNorm pass it replaces)
+                float2 st[MT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        int m = mw + mt * 16 + rowh + 8 * i;
+                        m = m < g.M ? m : g.M - 1;
+                        st[mt][i] = *(const float2*)(g.ln_stats + 2 * (int64_t)m);
+                    }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float mu = st[mt][i].x * ln_inv_d;
+                        const float rs = __builtin_amdgcn_rsqf(fmaxf(st[mt][i].y * ln_inv_d - mu * mu, 0.f) + g.ln_eps);
+                        ln_rs[mt][i] = rs;
+                        ln_c[mt][i] = mu * rs;
+                    }
+            }
             if (DBG == 4) { asm volatile("" ::"v"(bv[0][0]), "v"(bv[3][3])); tr3 = wall_clock64(); }
 #pragma clang loop unroll(full)
             for (int mt = 0; mt < MT; ++mt) {
@@ -585,6 +621,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        if (MODE == 1) { v[j] = acc[mt][nt][j] * alpha; continue; }
                         v[j] = acc[mt][nt][j] * alpha + bv[nt][j];
                         if (ACT != ACT_NONE && ACT != ACT_ABS_POST) v[j] = apply_act(v[j], ACT);
                     }
@@ -616,8 +653,39 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         const float4 t0 = *(const float4*)(eb + row * EP + (lane & 7) * 8);
                         const float4 t1 = *(const float4*)(eb + row * EP + (lane & 7) * 8 + 4);
                         float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                        if (MODE == 2) {
+                            float s1 = 0.f, s2 = 0.f;
+                            if (m < m_lim && nh < g.N) {
+                                if (g.res_hi) {
+                                    const int64_t ro = (int64_t)m * g.ldrh + nh;
+                                    const half8 rh = *(const half8*)((const half_t*)g.res_hi + ro);
+                                    const half8 rl = *(const half8*)((const half_t*)g.res_lo + ro);
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) v[j] += ((float)rh[j] + (float)rl[j]) * g.res_scale;
+                                }
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 += v[j] * v[j]; }
+                            }
+                            if (g.row_stats) {                             // the 8 lanes of a row: three exchange steps, one atomic pair
+                                s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+                                s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+                                s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+                                if ((lane & 7) == 0 && m < m_lim) {
+                                    atomicAdd(g.row_stats + 2 * (int64_t)m, s1);
+                                    atomicAdd(g.row_stats + 2 * (int64_t)m + 1, s2);
+                                }
+                            }
+                        }
+                        if (MODE == 1) {
+                            const float rstd = ln_rs[mt][i], c = ln_c[mt][i];      // c = mu * rstd
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                v[j] = fmaf(v[j], rstd, fmaf(-c, cs8[j], b8[j]));
+                                if (ACT != ACT_NONE && ACT != ACT_ABS_POST) v[j] = apply_act(v[j], ACT);
+                            }
+                        }
                         if (m < m_lim && nh < g.N) {
-                            if (g.residual) {
+                            if (MODE == 0 && g.residual) {
                                 const float* r = g.residual + zr + (int64_t)m * g.ldr + nh;
                                 const float4 r0 = *(const float4*)r, r1 = *(const float4*)(r + 4);
                                 v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
@@ -654,12 +722,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab fully read before it is overwritten
             }
         };
-        switch (g.act) {
-            case ACT_GELU: fast_epi(std::integral_constant<int, ACT_GELU>{}); break;
-            case ACT_QUICKGELU: fast_epi(std::integral_constant<int, ACT_QUICKGELU>{}); break;
-            case ACT_RELU: fast_epi(std::integral_constant<int, ACT_RELU>{}); break;
-            case ACT_ABS_POST: fast_epi(std::integral_constant<int, ACT_ABS_POST>{}); break;
-            default: fast_epi(std::integral_constant<int, ACT_NONE>{}); break;
+        typedef std::integral_constant<int, 0> mode0;
+        typedef std::integral_constant<int, 1> mode1;
+        typedef std::integral_constant<int, 2> mode2;
+        if (g.ln_stats) {                                                // launcher: out_hi only, act in {none, GELU, QuickGELU}
+            switch (g.act) {
+                case ACT_GELU: fast_epi(std::integral_constant<int, ACT_GELU>{}, mode1{}); break;
+                case ACT_QUICKGELU: fast_epi(std::integral_constant<int, ACT_QUICKGELU>{}, mode1{}); break;
+                default: fast_epi(std::integral_constant<int, ACT_NONE>{}, mode1{}); break;
+            }
+        } else if (g.res_hi || g.row_stats) {                            // launcher: out_hi only, act none
+            fast_epi(std::integral_constant<int, ACT_NONE>{}, mode2{});
+        } else {
+            switch (g.act) {
+                case ACT_GELU: fast_epi(std::integral_constant<int, ACT_GELU>{}, mode0{}); break;
+                case ACT_QUICKGELU: fast_epi(std::integral_constant<int, ACT_QUICKGELU>{}, mode0{}); break;
+                case ACT_RELU: fast_epi(std::integral_constant<int, ACT_RELU>{}, mode0{}); break;
+                case ACT_ABS_POST: fast_epi(std::integral_constant<int, ACT_ABS_POST>{}, mode0{}); break;
+                default: fast_epi(std::integral_constant<int, ACT_NONE>{}, mode0{}); break;
+            }
         }
         trace_end();
         return;
@@ -757,8 +838,11 @@ static int tail_parts(int rem, int K) {
     const int smax = 256 / rem < 4 ? 256 / rem : 4;
     int best = 1;
     double t = 0.0685 * K + 14.0;
+    // a split has to win by a margin: at K = 1280 / 128 tail tiles the model calls it even and the measurement does not
+    // (proj 32768 x 1280 x 1280: 312-355 us split, 303-338 us whole, tools/ab_tail.py)
+    double need = 0.92 * t;
     for (int S = 2; S <= smax; ++S)
-        if (K / 32 >= 4 * S && tail_us(S, K, rem) < t) { t = tail_us(S, K, rem); best = S; }
+        if (K / 32 >= 4 * S && tail_us(S, K, rem) < need) { t = need = tail_us(S, K, rem); best = S; }
     return best;
 }
 
@@ -787,6 +871,15 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (!g.out_f32 && !g.out_hi) return CVLM_E_BADARG;
     if (g.ps_c2 > 0 && ((g.ps_c2 & 3) || g.ps_h <= 0 || g.ps_w <= 0)) return CVLM_E_BADARG;
     if (g.hm_S > 0 && ((g.hm_hd & 3) || g.hm_H <= 0 || (g.M % g.hm_S) || g.N != 3 * g.hm_H * g.hm_hd || !g.out_hi)) return CVLM_E_BADARG;
+    const bool fold = g.ln_stats != nullptr, h2res = g.res_hi != nullptr || g.row_stats != nullptr;
+    if (fold || h2res) {
+        // these two epilogue forms exist on the LDS-staged path only: h2 output, 8-column row pieces, one problem per launch
+        if (fold && h2res) return CVLM_E_BADARG;
+        if (!g.out_hi || g.out_f32 || g.residual || g.ps_c2 > 0 || g.batch > 1) return CVLM_E_BADARG;
+        if ((g.N & 7) || (g.ldoh & 7) || (g.hm_S > 0 && ((g.hm_hd & 7) || g.hm_S < 128))) return CVLM_E_UNSUPPORTED;
+        if (fold && (!g.ln_colsum || g.ln_D <= 0 || (g.act != ACT_NONE && g.act != ACT_GELU && g.act != ACT_QUICKGELU))) return CVLM_E_BADARG;
+        if (h2res && (g.act != ACT_NONE || (g.res_hi && (!g.res_lo || (g.ldrh & 7))))) return CVLM_E_BADARG;
+    }
     GemmParams p;
     p.a = g;
     if (p.a.batch <= 0) p.a.batch = 1;

@@ -198,6 +198,26 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     }
 }
 
+// one wave per row: h2 = x * scale, stats = (sum x, sum x^2) of the unscaled row
+__global__ __launch_bounds__(256) void row_stats_split_kernel(const float* __restrict__ x, float scale, half_t* __restrict__ hi,
+                                                              half_t* __restrict__ lo, float* __restrict__ stats, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * D;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 t = *(const float4*)(xr + c);
+        s1 += (t.x + t.y) + (t.z + t.w);
+        s2 += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        const float o[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
+        store_h2x4(hi, lo, (int64_t)row * D + c, o);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { stats[2 * (int64_t)row] = s1; stats[2 * (int64_t)row + 1] = s2; }
+}
+
 __global__ __launch_bounds__(256) void dense_pe_kernel(const float* __restrict__ gauss, int size, int C,
                                                        float* __restrict__ out) {
     const int half = C >> 1;
@@ -503,6 +523,14 @@ int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, f
     const int64_t nvec = (int64_t)M * (D >> 2);
     hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(nvec)), dim3(256), 0, (hipStream_t)stream, a, b, b_rows, scale,
                        out_f32, (half_t*)out_hi, (half_t*)out_lo, nvec, D >> 2);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D, void* stream) {
+    if (!x || !out_hi || !out_lo || !stats || M <= 0 || D <= 0 || (D & 3)) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(row_stats_split_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, (half_t*)out_hi,
+                       (half_t*)out_lo, stats, M, D);
     CVLM_CHECK_LAUNCH();
     return 0;
 }

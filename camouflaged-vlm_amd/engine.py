@@ -36,13 +36,15 @@ class Precision:
 
 # Static power-of-two scales that keep UNBOUNDED activations inside fp16 range when they become h2 GEMM operands
 # (DESIGN.md §3): LayerNorm outputs are bounded by sqrt(D) * max|gamma| and everything downstream of them by the
-# weights; what is not bounded is (a) the raw residual stream where the reference feeds it to a Linear directly
-# (PromptGenerator.init_embeddings, image_encoder.py:278-281; the neck, :150) and (b) MLP hidden activations
-# (common.py:25, alpha_clip_rw/model.py:296-300).  Stored value = true value * scale; the consuming GEMM's alpha
-# carries 1 / scale.  Guaranteed range: |x| < 65504 / scale, i.e. 1.6e7 for the residual stream and 4.1e6 for hidden
-# units; absolute resolution of the planes 6e-8 / scale (1.5e-5 and 3.8e-6): far below the 1e-3 gate after the weights.
-X_SCALE = 2.0 ** -8
-HID_SCALE = 2.0 ** -6
+# weights; what is not bounded is (a) the raw residual stream (kept in h2 between the GEMMs of a block; fed to a Linear
+# directly by PromptGenerator.init_embeddings, image_encoder.py:278-281, and by the neck, :150) and (b) MLP hidden
+# activations (common.py:25, alpha_clip_rw/model.py:296-300).  Stored value = true value * scale; the consuming GEMM's
+# alpha carries 1 / scale.  Guaranteed range: |x| < 65504 / scale = 2.6e5.  The shift is kept small on purpose: the lo
+# plane of a value v is ~ v * 2^-11, and below 6.1e-5 fp16 goes subnormal (absolute step 6e-8) -- with 2^-8 / 2^-6
+# (first choice of this round) the lo planes of O(1) activations lost most of their bits and the tiny cascade's error
+# grew from 3e-5 to 1.4e-4; with 2^-2 values down to ~0.1 keep all 22 bits.
+X_SCALE = 2.0 ** -2
+HID_SCALE = 2.0 ** -2
 
 
 def _ceil(a: int, b: int) -> int:
@@ -111,6 +113,19 @@ class Linear:
             self.bias = bp.to(device)
 
 
+class LnLinear(Linear):
+    """Linear that consumes a LayerNorm, with the norm folded in (include/cvlm.h, cvlm_gemm_args.ln_stats):
+        Linear(LN(x)) = rstd * (x . W'^T - mu * colsum) + bias',   W' = W . diag(gamma),  bias' = bias + W . beta,
+    colsum[n] = sum_k W'[n][k] -- taken from the PACKED planes so that it is the sum of exactly the numbers the MFMAs see."""
+
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, device):
+        w = w.detach().double().reshape(w.shape[0], -1).cpu()
+        g, be = gamma.detach().double().cpu(), beta.detach().double().cpu()
+        b2 = (b.detach().double().cpu() if b is not None else torch.zeros(w.shape[0], dtype=torch.float64)) + w @ be
+        super().__init__((w * g[None, :]).float(), b2.float(), device)
+        self.colsum = (self.w.t.double().sum(0).sum(1) * self.alpha).float().contiguous()
+
+
 class _Base:
     def __init__(self, device, precision: Precision):
         self.device = device
@@ -175,6 +190,10 @@ class SamEncoder(_Base):
         self.lin2cat = [Linear(torch.cat([sd[P + f"blocks.{i}.mlp.lin2.weight"].detach().float().cpu(), shw], 1),
                                sd[P + f"blocks.{i}.mlp.lin2.bias"].detach().float().cpu() + shb, device)
                         for i in range(g.depth - 1)]
+        import os
+        # LayerNorm folded into the GEMMs that consume it + the residual stream kept in h2 between them: no LayerNorm
+        # kernels inside the blocks (64 launches, 4.5 ms per step at B = 8).  CVLM_LN_FOLD=0 restores the separate passes.
+        self.ln_fold = os.environ.get("CVLM_LN_FOLD", "1") == "1"
         self.blocks = []
         for i in range(g.depth):
             b = f"blocks.{i}."
@@ -186,6 +205,11 @@ class SamEncoder(_Base):
                 rel_h=H2(H2.pack(sd[P + b + "attn.rel_pos_h"].detach().float().cpu()).t.to(device)),
                 rel_w=H2(H2.pack(sd[P + b + "attn.rel_pos_w"].detach().float().cpu()).t.to(device)),
                 window=0 if i in g.global_attn_indexes else g.window_size)
+            if self.ln_fold:
+                blk["qkv_f"] = LnLinear(sd[P + b + "attn.qkv.weight"], sd[P + b + "attn.qkv.bias"],
+                                        sd[P + b + "norm1.weight"], sd[P + b + "norm1.bias"], device)
+                blk["lin1_f"] = LnLinear(sd[P + b + "mlp.lin1.weight"], sd[P + b + "mlp.lin1.bias"],
+                                         sd[P + b + "norm2.weight"], sd[P + b + "norm2.bias"], device)
             self.blocks.append(blk)
         self.neck0 = L("neck.0")
         w2 = sd[P + "neck.2.weight"].detach().float().cpu()                   # (O, I, 3, 3) -> (O, ky, kx, I)
@@ -253,6 +277,8 @@ class SamEncoder(_Base):
         hid = ws.h2("hid", M, HK)
         hid_prm = H2(hid.t[:, :, g.mlp_dim:])                      # the PK trailing columns (same row pitch)
         fold = taps is None                                        # block taps need x before the next prompt is added
+        if fold and self.ln_fold:
+            return self._blocks_folded(x, feat, prm, qkv, att, hid, hid_prm, B)
         for i, blk in enumerate(self.blocks):
             # :138/:145 prompt_i = shared_mlp(GELU(lightweight_mlp_i(feat))) ; x = prompt_i + x
             if i == 0 or not fold:
@@ -280,9 +306,52 @@ class SamEncoder(_Base):
                 self.gemm(hid, blk["lin2"], M, lda=HK, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
             if taps is not None:
                 taps[f"block{i}"] = x.clone()
-        # :150 neck (LayerNorm2d == row LN on NHWC)
-        C = g.out_chans
         hip.add_rows(x, None, 1, M, D, scale=X_SCALE, out_h2=xn)
+        return self._neck(xn, B)
+
+    def _blocks_folded(self, x, feat, prm, qkv, att, hid, hid_prm, B: int) -> torch.Tensor:
+        """The 32 blocks without LayerNorm passes.  The residual stream lives in h2 (xh = x * X_SCALE); proj and lin2
+        read it as their residual, write it back and leave the row sums (sum x, sum x^2) behind; qkv and lin1 consume
+        the un-normalised rows with the norm folded into their epilogue (LnLinear).  image_encoder.py:430-446."""
+        g, ws, pr = self.g, self.ws, self.prec
+        G, D, T = g.grid, g.embed_dim, g.grid * g.grid
+        M, HK = B * T, g.mlp_dim + self.PK
+        xh = ws.h2("xh", M, D)
+        st1, st2 = ws.f32("ln_st1", M, 2), ws.f32("ln_st2", M, 2)
+        self.gemm(feat, self.light[0], M, out_h2=prm, act=ACT_GELU)               # prompt of block 0 (:145)
+        self.gemm(prm, self.shared, M, residual=x, out_f32=x)
+        hip.row_stats_split(x, X_SCALE, xh, st1, M, D)
+        inv = 1.0 / X_SCALE
+        for i, blk in enumerate(self.blocks):
+            st2.zero_()
+            self.gemm(xh, blk["qkv_f"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim), alpha=inv,
+                      ln_fold=(st1, blk["qkv_f"].colsum, 1e-6, D))
+            if blk["window"] > 0:
+                self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
+                               pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
+                               head_major=True)
+            else:
+                self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
+                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
+            self.gemm(att, blk["proj"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=st2)
+            st1.zero_()
+            self.gemm(xh, blk["lin1_f"], M, out_h2=hid, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE, alpha=inv,
+                      ln_fold=(st2, blk["lin1_f"].colsum, 1e-6, D))
+            if i + 1 < g.depth:
+                self.gemm(feat, self.light[i + 1], M, out_h2=hid_prm, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE)
+                self.gemm(hid, self.lin2cat[i], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
+                          alpha=1.0 / HID_SCALE, row_stats=st1)
+            else:
+                self.gemm(hid, blk["lin2"], M, lda=HK, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
+                          alpha=1.0 / HID_SCALE)
+        return self._neck(xh, B)
+
+    def _neck(self, xn: H2, B: int) -> torch.Tensor:
+        """:150 neck (LayerNorm2d == row LN on NHWC); xn = x * X_SCALE in h2."""
+        g, ws = self.g, self.ws
+        G, D, T = g.grid, g.embed_dim, g.grid * g.grid
+        M = B * T
+        C = g.out_chans
         c1 = ws.f32("neck_c1", M, C)
         self.gemm(xn, self.neck0, M, out_f32=c1, alpha=1.0 / X_SCALE)
         hip.layernorm(c1, self.nk1[0], self.nk1[1], 1e-6, M, C, out_f32=c1)

@@ -23,9 +23,9 @@ EXPORTS = [
     "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
-    "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes",
+    "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split",
 ]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GemmArgs(C.Structure):
@@ -41,6 +41,9 @@ class GemmArgs(C.Structure):
         ("ps_h", C.c_int32), ("ps_w", C.c_int32), ("ps_c2", C.c_int32),
         ("hm_S", C.c_int32), ("hm_H", C.c_int32), ("hm_hd", C.c_int32),
         ("out_scale", C.c_float), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_D", C.c_int32),
+        ("res_hi", C.c_void_p), ("res_lo", C.c_void_p), ("ldrh", C.c_int64), ("res_scale", C.c_float),
+        ("row_stats", C.c_void_p),
     ]
 
 
@@ -166,7 +169,12 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          stride_a: int = 0, stride_w: int = 0, stride_r: int = 0, stride_o: int = 0, stride_oh: int = 0,
          pixel_shuffle: Optional[Tuple[int, int, int]] = None,
          head_major: Optional[Tuple[int, int, int]] = None, out_scale: float = 1.0,
-         workspace: Optional[torch.Tensor] = None) -> None:
+         workspace: Optional[torch.Tensor] = None,
+         ln_fold: Optional[Tuple[torch.Tensor, torch.Tensor, float, int]] = None,
+         residual_h2: Optional[Tuple["H2", float]] = None, ldrh: Optional[int] = None,
+         row_stats: Optional[torch.Tensor] = None) -> None:
+    """ln_fold = (stats [M][2] f32, colsum [N] f32, eps, D): LayerNorm of the input folded into this GEMM (include/cvlm.h);
+    residual_h2 = (x h2, scale): residual given as h2 planes; row_stats [M][2] f32: += (sum, sum of squares) of the result rows."""
     _on_current_device(a.t)
     g = GemmArgs()
     g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
@@ -184,6 +192,13 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     if head_major is not None:
         g.hm_S, g.hm_H, g.hm_hd = head_major
     g.out_scale = out_scale
+    if ln_fold is not None:
+        g.ln_stats, g.ln_colsum, g.ln_eps, g.ln_D = ln_fold[0].data_ptr(), ln_fold[1].data_ptr(), ln_fold[2], ln_fold[3]
+    if residual_h2 is not None:
+        r, rs = residual_h2
+        g.res_hi, g.res_lo, g.ldrh, g.res_scale = r.hi.data_ptr(), r.lo.data_ptr(), (ldrh if ldrh is not None else N), rs
+    if row_stats is not None:
+        g.row_stats = row_stats.data_ptr()
     if workspace is not None:
         g.workspace, g.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     _check(load().cvlm_gemm(C.byref(g), C.c_void_p(_stream())), "cvlm_gemm")
@@ -207,6 +222,12 @@ def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], b_rows: int, M: int, D:
         C.c_void_p(a.data_ptr()), C.c_void_p(_p(b)), C.c_int32(b_rows), C.c_float(scale), C.c_void_p(_p(out_f32)),
         C.c_void_p(out_h2.hi.data_ptr() if out_h2 else None), C.c_void_p(out_h2.lo.data_ptr() if out_h2 else None),
         C.c_int32(M), C.c_int32(D), C.c_void_p(_stream())), "cvlm_add_rows")
+
+
+def row_stats_split(x: torch.Tensor, scale: float, out: H2, stats: torch.Tensor, M: int, D: int) -> None:
+    _check(load().cvlm_row_stats_split(C.c_void_p(x.data_ptr()), C.c_float(scale), C.c_void_p(out.hi.data_ptr()),
+                                       C.c_void_p(out.lo.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_int32(M), C.c_int32(D),
+                                       C.c_void_p(_stream())), "cvlm_row_stats_split")
 
 
 def split_f32(x: torch.Tensor, out: H2) -> None:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 2
+#define CVLM_ABI_VERSION 3
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -72,6 +72,18 @@ typedef struct cvlm_gemm_args {
     float out_scale;             /* ABI 2 */
     void* workspace;             /* ABI 2 */
     int64_t workspace_bytes;     /* ABI 2 */
+    /* ABI 3 -- LayerNorm folded into the GEMM that consumes it (image_encoder.py:432,444 + :491 / common.py:25): with
+     * W' = W.diag(gamma) packed as the weight, bias' = bias + W.beta and ln_colsum[n] = sum_k W'[n][k],
+     *     out = act( rstd_m * (alpha * acc - mu_m * ln_colsum[n]) + bias'[n] ),   mu = s1 / ln_D,  rstd = 1 / sqrt(s2 / ln_D - mu^2 + ln_eps)
+     * where (s1, s2) = ln_stats[m] are the sums of x and x^2 over row m of the UN-normalised input (A holds x, possibly
+     * scaled: alpha carries the inverse).  h2 output only, act in {NONE, GELU, QUICKGELU}, N % 8 == 0. */
+    const float* ln_stats; const float* ln_colsum; float ln_eps; int32_t ln_D;
+    /* ABI 3 -- the producer side: residual given as h2 planes (value = (hi + lo) * res_scale, leading dimension ldrh) and
+     * row_stats[m] += (sum_n v, sum_n v^2) of the final values v of this launch's columns (atomic adds: zero it first).
+     * h2 output only, act NONE, N % 8 == 0.  Together the two forms keep a pre-norm residual stream in h2 between the
+     * GEMMs of a transformer block with no separate LayerNorm pass. */
+    const void* res_hi; const void* res_lo; int64_t ldrh; float res_scale;
+    float* row_stats;
 } cvlm_gemm_args;
 int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
 int64_t cvlm_gemm_workspace_bytes(void);
@@ -90,6 +102,10 @@ int cvlm_layernorm(const float* x, int64_t ldx, const float* add, int32_t add_ro
  * transformer_maskdecoder_edge.py:177-209, mask_decoder_edge.py:157). */
 int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, float* out_f32,
                   void* out_hi, void* out_lo, int32_t M, int32_t D, void* stream);
+
+/* Row statistics + split: out h2 = x * scale (both planes), stats[m] = (sum_d x, sum_d x^2) of the unscaled row (overwritten).
+ * Seeds the h2 residual stream of the LayerNorm-folded GEMMs (cvlm_gemm_args.ln_stats) from an f32 tensor x [M][D]. */
+int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D, void* stream);
 
 /* f32 -> h2 planes (elementwise split), n elements.  No reference counterpart: it produces the operand format of
  * cvlm_gemm / cvlm_attention from tensors the reference keeps in fp32 (e.g. the sparse prompts, models/sam_maskdecoder_edge.py:342-344). */

@@ -126,6 +126,54 @@ def test_gemm_tail_split(hip, M, N, K, why, monkeypatch):
     assert int(ws[:2048].view(torch.int32).abs().sum()) == 0                           # hand-off words are back to zero
 
 
+@pytest.mark.parametrize("M,D,N,act", [(700, 160, 480, 0), (4096 + 40, 1280, 768, 1), (520, 1024, 264, 2)])
+def test_gemm_layernorm_fold_and_h2_residual(hip, M, D, N, act):
+    """The pair of epilogue forms that keep a pre-norm residual stream in h2 (include/cvlm.h, ABI 3):
+    producer: x_new = a0 . w0^T + b0 + x_old (residual as h2 planes), stored as h2 and leaving (sum, sum of squares) per row;
+    consumer: act(LayerNorm(x_new) . W^T + b) computed from the UN-normalised x_new with the norm folded into the GEMM.
+    Rows carry massive channels (x 1e3) like real ViT residual streams."""
+    from camouflaged_vlm_amd.engine import LnLinear, Linear
+    K0, XS = 96, 2.0 ** -8
+    x_old = rnd(M, D, seed=71)
+    x_old[:, 3] *= 1e3
+    x_old[:, D // 2] *= 300.0
+    a0, w0, b0 = rnd(M, K0, seed=72), rnd(D, K0, seed=73, scale=0.1), rnd(D, seed=74)
+    gamma, beta = 1.0 + 0.1 * rnd(D, seed=75), 0.05 * rnd(D, seed=76)
+    W, b = rnd(N, D, seed=77, scale=D ** -0.5), rnd(N, seed=78, scale=0.05)
+    dev = "cuda"
+    # ---- producer
+    xh = hip.H2.pack(x_old * XS)
+    xh = hip.H2(xh.t.to(dev))
+    lin0 = Linear(w0, b0, dev)
+    A0 = dev_h2(hip, a0)
+    stats = torch.zeros(M, 2, device=dev)
+    hip.gemm(A0, lin0.w, M, D, lin0.K, bias=lin0.bias, alpha=lin0.alpha, out_h2=xh, residual_h2=(xh, 1.0 / XS), out_scale=XS,
+             row_stats=stats)
+    x_ref = A0.float().cpu().double() @ w0.double().t() + b0.double() + hip.H2.pack(x_old * XS).float().double() / XS
+    got = xh.float().cpu().double() / XS
+    assert relerr(got, x_ref) < 3e-6
+    s_ref = torch.stack([x_ref.sum(1), (x_ref * x_ref).sum(1)], 1)
+    s_mag = torch.stack([x_ref.abs().sum(1), (x_ref * x_ref).sum(1)], 1)           # fp32 sums: error relative to sum |x|
+    assert float(((stats.cpu().double() - s_ref).abs() / s_mag).max()) < 2e-6
+    # ---- consumer
+    lin = LnLinear(W, b, gamma, beta, dev)
+    out = hip.H2.empty(M, N, device=dev)
+    out.t.fill_(float("nan"))
+    hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=act, out_h2=out, out_scale=0.25,
+             ln_fold=(stats, lin.colsum, 1e-6, D))
+    xn = F.layer_norm(got, (D,), gamma.double(), beta.double(), 1e-6)
+    z = xn @ W.double().t() + b.double()
+    z = {0: z, 1: F.gelu(z), 2: z * torch.sigmoid(1.702 * z)}[act]
+    err = float((out.float().cpu().double() / 0.25 - z).abs().max())
+    print(f"LN-fold GEMM M={M} D={D} N={N} act={act}: max abs err {err:.2e} (|z| max {float(z.abs().max()):.1f})")
+    assert err < 2e-5 * max(1.0, float(z.abs().max()))
+    # the row kernel that seeds the stream gives the same planes and statistics as the producer
+    xh2, st2 = hip.H2.empty(M, D, device=dev), torch.empty(M, 2, device=dev)
+    hip.row_stats_split(x_ref.float().to(dev), XS, xh2, st2, M, D)
+    assert relerr(xh2.float().cpu().double() / XS, x_ref) < 3e-7
+    assert float(((st2.cpu().double() - s_ref).abs() / s_mag).max()) < 2e-6
+
+
 def to_head_major(qkv, Bn, S, Hh, hd):
     """[B*S][3][H][hd] -> [3][B][H][S][hd] flattened back to the same (B*S, 3*H*hd) buffer shape."""
     return qkv.reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).contiguous().reshape(Bn * S, 3 * Hh * hd)
