@@ -283,7 +283,7 @@ def main():
             hip.gemm, hip.attention = orig, orig_attn
             cas.overlap_clip = was_overlap
         traffic, tnote = None, None
-        for tname in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        for tname in ("r02_gemm_traffic.json",):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             tfile = os.path.join(REPO, "profiles", tname)
             if args.geometry == "demo" and args.precision == "exact" and B == 8 and os.path.exists(tfile):
                 with open(tfile) as f:
@@ -295,7 +295,7 @@ def main():
         ms = sum(r[1].elapsed_time(r[2]) for r in records)
         achieved = flops / (ms * 1e-3) / 1e12
         secondary = []
-        for name, kern in (("global", "attn_g64pp_kernel (ViT-H global attention, 64x64 map)"),
+        for name, kern in (("global", "attn_g64pair_kernel (ViT-H global attention, 64x64 map)"),
                            ("window", "attn_win14_kernel (ViT-H 14x14 window attention)")):
             rs = arecs[name]
             if rs:

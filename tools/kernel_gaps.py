@@ -10,9 +10,9 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 short = lambda n: re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", ""))[:60]
-# last third of the trace = steady-state steps
+# middle third of the trace = steady-state steps (the head holds weight uploads, the tail the parity check and CPU work)
 n = len(rows)
-part = rows[n * 2 // 3:]
+part = rows[n // 3: n * 2 // 3]
 busy = sum(e - s for s, e, _ in part)
 wall = part[-1][1] - part[0][0]
 gaps = collections.defaultdict(lambda: [0, 0])

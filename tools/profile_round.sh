@@ -1,0 +1,34 @@
+set -x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/prof_r2
+rm -rf $O; mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 4 --warmup 2 --no-overlap --no-cpu-baseline > $O/bench_stats.log 2>&1
+python tools/summarize_profiles.py stats $O/stats $O/r02_bench_exact_b8_kernel_stats.csv
+python tools/kernel_gaps.py $O/stats > $O/r02_kernel_gaps.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-roofline > $O/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-roofline > $O/bench_write.log 2>&1
+python tools/summarize_profiles.py traffic $O/fetch $O/write $O/r02_gemm_traffic.json "gemm_nt_kernel<3"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python3 bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-roofline > $O/bench_sq.log 2>&1
+python - <<'PY'
+import csv, glob, collections, json
+f = sorted(glob.glob("gpurun_out/prof_r2/sq/**/*_counter_collection.csv", recursive=True))[-1]
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for r in csv.DictReader(open(f)):
+    k = r["Kernel_Name"]
+    k = "gemm 256^2" if "gemm_nt_kernel<3, 2, 4, 5" in k else "gemm 256x128" if "gemm_nt_kernel<3, 4, 2, 3" in k else "attn global" if "g64pair" in k else "attn window" if "attn_win14" in k else None
+    if k is None: continue
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+    if r["Counter_Name"] == "SQ_WAVE_CYCLES": cnt[k] += 1
+out = {}
+for k, d in agg.items():
+    # SQ_WAVE_CYCLES etc. count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; GRBM_GUI_ACTIVE is summed over 8 XCDs
+    gui = d["GRBM_GUI_ACTIVE"] / 8.0
+    out[k] = {"launches": cnt[k], "mfma_busy_frac_of_simd_time": d["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024.0) if gui else None,
+              "wait_any_frac": d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"], "wait_inst_any_frac": d["SQ_WAIT_INST_ANY"] / d["SQ_WAVE_CYCLES"],
+              "active_inst_any_frac": d["SQ_ACTIVE_INST_ANY"] / d["SQ_WAVE_CYCLES"], "gui_active_cycles_per_launch": gui / max(cnt[k], 1)}
+json.dump(out, open("gpurun_out/prof_r2/r02_sq_counters.json", "w"), indent=1); print(json.dumps(out, indent=1))
+PY
+python bench.py --geometry hires1536 --batch 4 --workload encoder --steps 5 --warmup 2 > $O/bench_1536.json 2>/dev/null; cat $O/bench_1536.json
+python bench.py --workload encoder --steps 5 --warmup 2 > $O/bench_enc.json 2>/dev/null; cat $O/bench_enc.json
+rm -rf $O/stats $O/fetch $O/write $O/sq
+ls -la $O
