@@ -237,8 +237,10 @@ class SamEncoder(_Base):
                  stride_w=2 * N * N, stride_r=N * N, stride_o=N * N, split=sp)
         return out
 
-    def forward(self, inp: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-        """inp (B,3,S,S) f32 on device -> features f32 [B*G*G][out_chans] (token-major NHWC)."""
+    def forward(self, inp: torch.Tensor, taps: Optional[dict] = None, out_name: str = "features") -> torch.Tensor:
+        """inp (B,3,S,S) f32 on device -> features f32 [B*G*G][out_chans] (token-major NHWC), in workspace buffer
+        `out_name` (a caller that keeps two batches in flight alternates two names)."""
+        self._out_name = out_name
         g, ws, pr = self.g, self.ws, self.prec
         B = inp.shape[0]
         assert inp.shape[1:] == (3, g.inp_size, g.inp_size), \
@@ -357,7 +359,7 @@ class SamEncoder(_Base):
         hip.layernorm(c1, self.nk1[0], self.nk1[1], 1e-6, M, C, out_f32=c1)
         col = ws.h2("neck_col", M, 9 * C)
         hip.im2col3x3(c1, B, G, G, C, col)
-        feats = ws.f32("features", M, C)
+        feats = ws.f32(getattr(self, "_out_name", "features"), M, C)
         self.gemm(col, self.neck2, M, out_f32=feats)
         hip.layernorm(feats, self.nk3[0], self.nk3[1], 1e-6, M, C, out_f32=feats)
         return feats
@@ -825,6 +827,8 @@ class Cascade(_Base):
         # which blurs per-kernel evidence.
         self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "1") == "1"
         self._side = None
+        self._done = [None, None]                                    # side-stream completion events of the last two batches
+        self._parity = 0
 
     def sparse_prompts(self, img_f: torch.Tensor, txt_f: torch.Tensor, B: int) -> torch.Tensor:
         """models/sam_maskdecoder_edge.py:342-344."""
@@ -874,23 +878,46 @@ class Cascade(_Base):
         return self.clip.forward(clip_image, alpha)
 
     def cascade(self, inp, clip_image, clip_mask, pipelined: bool = False):
-        """Stage 1 + stage 2.  With the side stream enabled, stage 2 (CLIP pass 2: 1.2-round GEMM grids) runs there.
-        pipelined=False: the current stream waits for it before returning (plain stream semantics for the caller).
-        pipelined=True: it does not -- the caller's next batch starts its SAM encoder underneath this batch's stage 2
-        (a serving loop: results are complete after `torch.cuda.synchronize()` / once the side stream has been waited
-        for; the next `cascade()` call orders itself behind it)."""
-        masks = self.infer_test(inp, clip_image, clip_mask)
+        """Stage 1 + stage 2.  With the side stream enabled only the SAM encoder runs on the caller's stream; CLIP pass
+        1, the sparse prompts, the mask decoder (hundreds of launches of a few workgroups each), the resize and stage 2
+        run on the side stream.
+        pipelined=False: the current stream waits for the side stream before returning (plain stream semantics).
+        pipelined=True: it does not -- the caller's next batch starts its encoder underneath this batch's decoder and
+        stage 2 (a serving loop: results are complete after `torch.cuda.synchronize()` or once the side stream has been
+        waited for; the next `cascade()` orders itself behind the previous one, at most one batch is in flight there)."""
         if not self.overlap_clip:
+            masks = self.infer_test(inp, clip_image, clip_mask)
             _, _, pred, logits = self.stage2(masks, clip_image)
             return masks, pred, logits
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        g, B = self.g, inp.shape[0]
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main, side = torch.cuda.current_stream(), self._side
+        # the batch before the previous one has left the side stream: its decoder read the features buffer this encoder
+        # run is about to overwrite (two buffers alternate)
+        if self._done[self._parity] is not None:
+            main.wait_event(self._done[self._parity])
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
+        feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+        enc_done = torch.cuda.Event()
+        enc_done.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(enc_done)
+            sparse = self.sparse_prompts(img_f, txt_f, B)
+            low = self.decoder.forward(feats, sparse, self.no_mask, self.gauss, B, None)
+            masks = torch.empty(B, 1, g.inp_size, g.inp_size, device=self.device)
+            hip.bilinear(low, B, 4 * g.grid, 4 * g.grid, masks, g.inp_size, g.inp_size)
             _, _, pred, logits = self.stage2(masks, clip_image)
-        for t in (masks, clip_image):
-            t.record_stream(self._side)
-        for t in (pred, logits):
+            done = torch.cuda.Event()
+            done.record(side)
+        self._done[self._parity] = done
+        self._parity ^= 1
+        for t in (inp, clip_image, clip_mask):
+            t.record_stream(side)
+        for t in (masks, pred, logits):
             t.record_stream(main)
         if not pipelined:
-            main.wait_stream(self._side)
+            main.wait_stream(side)
         return masks, pred, logits

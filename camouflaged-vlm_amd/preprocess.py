@@ -1,6 +1,10 @@
 """GPU preprocessing in front of the hot path: uint8 HWC image on the device ->
-``inp`` (1,3,S,S), ``clip_image`` (1,3,R,R), ``clip_mask`` (1,1,R,R) exactly as demo.py:93-107 /
-datasets/wrappers.py:22-62 build them with torchvision + Pillow on the CPU.  The coefficient tables of
+``inp`` (1,3,S,S), ``clip_image`` (1,3,R,R), ``clip_mask`` (1,1,R,R).  ``inp`` and ``clip_image`` are exactly what
+demo.py:93-101 / datasets/wrappers.py:22-62 build with torchvision + Pillow on the CPU.  ``clip_mask`` follows the
+DATASET WRAPPER by default (a uint8 all-255 mask through ToTensor + Normalize(0.5, 0.26): 1.923, wrappers.py:62, the value
+the model is trained and evaluated with); demo.py:103 builds its mask from a float64 array (PIL mode 'F'), which
+ToTensor does not divide by 255, so the demo script feeds (255 - 0.5) / 0.26 = 978.8 instead -- `convention="demo"`
+reproduces that.  The coefficient tables of
 Pillow's resample are computed on the host once per (in, out, filter) and cached; all per-pixel work is in
 camouflaged-vlm_amd/csrc/preprocess.hip."""
 from __future__ import annotations
@@ -100,9 +104,13 @@ class GpuPreprocess:
         hip.u8_to_tensor(r, top, left, R, R, self.cl_mean, self.cl_std, out)
         return out
 
-    def clip_mask(self, n: int) -> torch.Tensor:
-        """mask_transform on an all-255 mask (wrappers.py:62): the constant (1 - 0.5) / 0.26."""
-        return torch.full((n, 1, self.R, self.R), (1.0 - 0.5) / 0.26, dtype=torch.float32, device=self.device)
+    def clip_mask(self, n: int, convention: str = "wrapper") -> torch.Tensor:
+        """mask_transform on an all-ones mask: "wrapper" = (1 - 0.5) / 0.26 (uint8 mask, wrappers.py:62);
+        "demo" = (255 - 0.5) / 0.26 (demo.py:103: float64 array, not rescaled by ToTensor)."""
+        if convention not in ("wrapper", "demo"):
+            raise ValueError(f"unknown clip_mask convention {convention!r}")
+        v = (1.0 - 0.5) / 0.26 if convention == "wrapper" else (255.0 - 0.5) / 0.26
+        return torch.full((n, 1, self.R, self.R), v, dtype=torch.float32, device=self.device)
 
     def __call__(self, img: torch.Tensor):
         if img.dim() == 3:
