@@ -37,6 +37,7 @@ struct GemmParams {
     // round are cut into `tail_split` K-parts, one workgroup each; parts 0..S-2 leave f32 partial slabs in `ws`
     // and raise `flags` (chain: part k adds part k-1's running sum), part S-1 (highest block index) runs the epilogue.
     int tail_rem, tail_split;
+    int total_blocks;  // PERSIST: workgroup b walks ids b, b + gridDim.x, ... < total_blocks
     float* ws;
     unsigned* flags;   // [tail_rem][4] arrival words (1 when ready; the consumer puts 0 back), then one error word at [4 * 128]
 #ifdef CVLM_PROBES
@@ -46,8 +47,12 @@ struct GemmParams {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4>
+// PERSIST (256^2 staggered kernel, no tail parts): one workgroup per CU walks the tile list; the first K-tile of the
+// next tile is requested before the epilogue of the current one, so the tile prologue (address set-up + first DMA latency,
+// ~4 us of a ~110 us K = 1280 tile) runs under the epilogue's stores.  The epilogue stages through LDS behind slot 0.
+template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
+    static_assert(!PERSIST || NSTAGE == 5, "persistent form exists for the staggered 256^2 loop only");
     constexpr int WROWS = MT * 16;                                  // activation rows per wave
     constexpr int BM = WM * WROWS, BN = WN * 64, NWAVE = WM * WN;
     constexpr int NPA = (SPLIT == 3) ? 2 : 1;                       // planes per operand
@@ -69,45 +74,48 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     [[maybe_unused]] unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, tr3 = 0, tr4 = 0;   // DBG == 4 timeline stamps
     if (DBG == 4) tr0 = wall_clock64();
 
-    // ---- tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
     const int ntiles = p.nbx * p.nby;
-    int pid = blockIdx.x;
-    int kpart = 0, kparts = 1, tail_j = 0;
-    if (NSTAGE == 5 && p.tail_rem > 0 && pid >= ntiles - p.tail_rem) {
-        const int j = pid - (ntiles - p.tail_rem);
-        kparts = p.tail_split;
-        kpart = j / p.tail_rem;                                      // producers first, the owner (S-1) last
-        tail_j = j - kpart * p.tail_rem;
-        pid = ntiles - p.tail_rem + tail_j;
-    }
-    {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = pid & 7, idx = pid >> 3;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // grouped order: the workgroups co-resident on one XCD cover a (group_m x n) patch of tiles, so each
-    // A / W k-slice they stream is fetched from HBM/L3 once and hit in the XCD's L2 afterwards.
-    int by, bx;
-    {
-        const int per_group = p.group_m * p.nbx;
-        const int grp = pid / per_group;
-        const int first = grp * p.group_m;
-        const int gm = (p.nby - first) < p.group_m ? (p.nby - first) : p.group_m;
-        const int rem = pid - grp * per_group;
-        by = first + rem % gm;
-        bx = rem / gm;
-    }
-    const int bm = by * BM, bn = bx * BN;
     const int z = blockIdx.y;
-
     const half_t* Ahi = (const half_t*)g.a_hi + (int64_t)z * g.stride_a;
     const half_t* Alo = (const half_t*)g.a_lo + (int64_t)z * g.stride_a;
     const half_t* Whi = (const half_t*)g.w_hi + (int64_t)z * g.stride_w;
     const half_t* Wlo = (const half_t*)g.w_lo + (int64_t)z * g.stride_w;
 
-    // ---- staging assignment.  Stage layout: [Ahi][Alo][Whi][Wlo]; instruction i covers 16 rows x 64 B.
+    // ---- per-tile state (set_tile): coordinates, K range, DMA source of every staging instruction of this wave
+    int bm = 0, bn = 0, kpart = 0, kparts = 1, tail_j = 0, nk = 0;
     const half_t* src[PER_WAVE];
-    int dst_off[PER_WAVE];
-    {
+    int dst_off[PER_WAVE];                                            // stage layout: [Ahi][Alo][Whi][Wlo]; instruction i covers 16 rows x 64 B
+    // Everything a run-time ?: selects between comes in as a parameter or is a local of the body: a conditional between two
+    // by-reference captures becomes a run-time index into the closure, which pins it -- and every capture -- in scratch.
+    auto set_tile_ = [&](int pid, const half_t* ahi, const half_t* alo, const half_t* whi, const half_t* wlo,
+                         int64_t lda_, int64_t ldw_, int M_, int N_) {
+        // tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
+        kpart = 0; kparts = 1; tail_j = 0;
+        if (NSTAGE == 5 && !PERSIST && p.tail_rem > 0 && pid >= ntiles - p.tail_rem) {
+            const int j = pid - (ntiles - p.tail_rem);
+            kparts = p.tail_split;
+            kpart = j / p.tail_rem;                                      // producers first, the owner (S-1) last
+            tail_j = j - kpart * p.tail_rem;
+            pid = ntiles - p.tail_rem + tail_j;
+        }
+        {
+            const int q = ntiles >> 3, r = ntiles & 7, xcd = pid & 7, idx = pid >> 3;
+            pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        // grouped order: the workgroups co-resident on one XCD cover a (group_m x n) patch of tiles, so each
+        // A / W k-slice they stream is fetched from HBM/L3 once and hit in the XCD's L2 afterwards.
+        int by, bx;
+        {
+            const int per_group = p.group_m * p.nbx;
+            const int grp = pid / per_group;
+            const int first = grp * p.group_m;
+            const int gm = (p.nby - first) < p.group_m ? (p.nby - first) : p.group_m;
+            const int rem = pid - grp * per_group;
+            by = first + rem % gm;
+            bx = rem / gm;
+        }
+        const int bm_ = by * BM, bn_ = bx * BN;
+        bm = bm_; bn = bn_;
         const int rsub = lane / CPR;                                  // row within the instruction's row group
         const int pos = lane % CPR;                                   // LDS chunk position within the row
 #pragma unroll
@@ -120,15 +128,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             const int row = sub * RPI + rsub;
             // source chunk for this LDS position (involution; BK=32: 4-chunk rows, BK=64: 8-chunk rows)
             const int chunk = (BK == 32) ? (pos ^ swz4((row >> 2) & 3)) : (pos ^ ((row >> 1) & 7));
-            const half_t* base = isW ? (plane ? Wlo : Whi) : (plane ? Alo : Ahi);
-            const int64_t ld = isW ? g.ldw : g.lda;
-            int grow = (isW ? bn : bm) + row;
-            const int lim = (isW ? g.N : g.M) - 1;
+            const half_t* base = isW ? (plane ? wlo : whi) : (plane ? alo : ahi);
+            const int64_t ld = isW ? ldw_ : lda_;
+            int grow = (isW ? bn_ : bm_) + row;
+            const int lim = (isW ? N_ : M_) - 1;
             grow = grow < lim ? grow : lim;
             src[j] = base + (int64_t)grow * ld + chunk * 8;
             dst_off[j] = (isW ? NPA * A_PLANE + plane * W_PLANE : plane * A_PLANE) + sub * 1024;
         }
-    }
+        nk = g.K / BK;
+        if (NSTAGE == 5 && kparts > 1) {                                 // this workgroup's share of the K-tiles
+            const int base = nk / kparts, extra = nk - base * kparts;
+            const int k0 = kpart * base + (kpart < extra ? kpart : extra);
+            nk = base + (kpart < extra ? 1 : 0);
+#pragma unroll
+            for (int j = 0; j < PER_WAVE; ++j) src[j] += (int64_t)k0 * BK;
+        }
+    };
+    auto set_tile = [&](int pid) { set_tile_(pid, Ahi, Alo, Whi, Wlo, g.lda, g.ldw, g.M, g.N); };
+    int vblk = blockIdx.x;
+    set_tile(vblk);
 
     // ---- fragment read offsets (bytes within a plane)
     const int fr = lane & 15, fq = lane >> 4;
@@ -139,20 +158,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     };
 
     floatx4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    int nk_ = g.K / BK;
-    if (NSTAGE == 5 && kparts > 1) {                                 // this workgroup's share of the K-tiles
-        const int base = nk_ / kparts, extra = nk_ - base * kparts;
-        const int k0 = kpart * base + (kpart < extra ? kpart : extra);
-        nk_ = base + (kpart < extra ? 1 : 0);
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) src[j] += (int64_t)k0 * BK;
-    }
-    const int nk = nk_;
     auto issue = [&](int t, int slot) {
         if (DBG == 1 && t > 1) return;                       // timing probe: no DMA in the steady state
 #pragma unroll
@@ -218,6 +223,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         }
     };
 
+    bool first_tile = true;
+  for (;;) {                                                 // tile loop: one pass unless PERSIST
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     if (NSTAGE == 2) {
         issue(0, 0);
         __syncthreads();                                     // emits vmcnt(0) for the in-flight DMA
@@ -393,10 +404,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 if (SPLIT == 3) wl[i] = *(const half8*)(pWhi + W_PLANE + w_row + i * 16 * ROWB + co);
             }
         };
-        // prologue: tile 0 resident for everyone; group B also launches its share of tile 1 (its "P1(-1)")
-        issue(0, 0);
-        if (grpB && nk > 1) { issue(1, 1); wait_vmcnt<PER_WAVE>(); }   // B's share of tile 1 rides behind tile 0
-        else wait_vmcnt<0>();
+        // prologue: tile 0 resident for everyone; group B also launches its share of tile 1 (its "P1(-1)").
+        // PERSIST, later tiles: both were requested before the previous epilogue and waited for inside it (every wave
+        // its own share): only the barrier is left.
+        if (!PERSIST || first_tile) {
+            issue(0, 0);
+            if (grpB && nk > 1) { issue(1, 1); wait_vmcnt<PER_WAVE>(); }   // B's share of tile 1 rides behind tile 0
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         if (DBG == 4) tr1 = wall_clock64();
         if (grpB) __builtin_amdgcn_s_barrier();                  // B starts one phase late
@@ -407,7 +422,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             read_a(cur, 0);
             mfma_half(0, grpB ? -1 : t + 1, (t + 1) & 1);        // group A streams tile t+1 under its P0
             read_a(cur, 1);                                       // second-half fragments: in flight across the barrier
-            if (grpB) wait_vmcnt<0>();                            // B's share of tile t+1 (issued one phase ago)
+            // B's share of tile t+1 (issued one phase ago).  PERSIST: at t = 0 of a later tile that share landed during the
+            // previous epilogue, and a vmcnt(0) here would wait for that epilogue's stores (vmcnt retires in issue order)
+            if (grpB && !(PERSIST && !first_tile && t == 0)) wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every fragment of tile t is in registers
             __builtin_amdgcn_s_barrier();
             // ---- P1
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 
     if (DBG == 4) tr2 = wall_clock64();
     int m_lim = g.M;
-    if (NSTAGE == 5 && kparts > 1) {
+    if (NSTAGE == 5 && !PERSIST && kparts > 1) {
         // K-parts of one tile reduce along a chain: part k waits for part k-1's slab, adds it to its accumulators
         // and (unless it is the last part, which runs the epilogue) publishes the running sum as its own slab;
         // the order of the fp32 additions is fixed.  (Written as "owner reads all slabs | others store", two
@@ -528,6 +545,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
+    // PERSIST: request the next tile's first K-tiles now (both slots are free after the last barrier of the main loop);
+    // the epilogue below works on copies of this tile's coordinates and stages through LDS behind the ring
+    const int e_bm = bm, e_bn = bn;
+    bool more = false;
+    if (PERSIST) {
+        const int vn = vblk + (int)gridDim.x;
+        more = vn < p.total_blocks;
+        if (more) {
+            vblk = vn; set_tile(vn); issue(0, 0);
+            if (__builtin_amdgcn_readfirstlane(tid) >= (NWAVE / 2) * 64 && nk > 1) issue(1, 1);    // group B: its share of K-tile 1
+        }
+    }
     // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
     const float alpha = g.alpha;
     const float oscale = g.out_scale;                                // h2 planes carry value * oscale (launcher maps 0 -> 1)
@@ -539,7 +568,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     float bv[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int n = bn + wn * 64 + nt * 16 + fq * 4;
+        const int n = e_bn + wn * 64 + nt * 16 + fq * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[nt][j] = (g.bias && !g.ln_stats && n + j < g.N) ? g.bias[n + j] : 0.f;
     }
@@ -559,16 +588,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         auto fast_epi = [&](auto act_c, auto mode_c) {
             constexpr int ACT = decltype(act_c)::value;
             constexpr int MODE = decltype(mode_c)::value;
-            constexpr int EP = 68;                                    // floats per staged row (64 + 4 pad)
+            // floats per staged row: 64 + 4 pad; PERSIST: 64, the 16-byte chunks of row r permuted by ^ r instead (the ring
+            // keeps its 128 KB, so the slabs of the 8 waves have to fit the last 32 KB of the CU's 160)
+            constexpr int EP = PERSIST ? 64 : 68;
             constexpr int LDS_BYTES = (NSTAGE == 6 ? 1 : (NSTAGE >= 4 ? 2 : NSTAGE)) * STAGE;
-            constexpr int NBUF = (LDS_BYTES >= NWAVE * 2 * 16 * EP * 4) ? 2 : 1;   // two slabs in flight when LDS allows
-            float* ebuf = (float*)smem + wave * (NBUF * 16 * EP);
-            const int n0 = bn + wn * 64;
+            constexpr int NBUF = (!PERSIST && LDS_BYTES >= NWAVE * 2 * 16 * EP * 4) ? 2 : 1;   // two slabs in flight when LDS allows
+            float* ebuf = (float*)(smem + (PERSIST ? 2 * STAGE : 0)) + wave * (NBUF * 16 * EP);
+            auto sw = [&](int row, int chunk) -> int { return PERSIST ? ((chunk ^ row) << 2) : (chunk << 2); };   // float offset of a 16-byte chunk
+            const int n0 = e_bn + wn * 64;
             const int64_t zo = (int64_t)z * g.stride_o, zr = (int64_t)z * g.stride_r, zh = (int64_t)z * g.stride_oh;
             // per-lane constants of the two store shapes
             const int rowf = lane >> 4, nf = n0 + (lane & 15) * 4;    // f32: 4 rows x 256 B per instruction
             const int rowh = lane >> 3, nh = n0 + (lane & 7) * 8;     // h2:  8 rows x 128 B per instruction and plane
-            const int mw = bm + wm * WROWS;                           // first row of this wave
+            const int mw = e_bm + wm * WROWS;                           // first row of this wave
             int64_t hm_col = 0, hm_bstride = 0;
             int hm_b = 0, hm_t = 0;                                   // image / token of row mw + rowh
             if (g.hm_S > 0) {                                         // head-major qkv store (8 | hd): column part once
@@ -625,7 +657,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         v[j] = acc[mt][nt][j] * alpha + bv[nt][j];
                         if (ACT != ACT_NONE && ACT != ACT_ABS_POST) v[j] = apply_act(v[j], ACT);
                     }
-                    *(float4*)(eb + fr * EP + nt * 16 + fq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(eb + fr * EP + sw(fr, nt * 4 + fq)) = make_float4(v[0], v[1], v[2], v[3]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (g.out_f32) {
@@ -633,7 +665,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     for (int i = 0; i < 4; ++i) {
                         const int row = rowf + 4 * i;
                         const int m = m0 + row;
-                        float4 t = *(const float4*)(eb + row * EP + (lane & 15) * 4);
+                        float4 t = *(const float4*)(eb + row * EP + sw(row, lane & 15));
                         if (m < m_lim && nf < g.N) {
                             if (g.residual) {
                                 const float4 r = *(const float4*)(g.residual + zr + (int64_t)m * g.ldr + nf);
@@ -650,8 +682,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     for (int i = 0; i < 2; ++i) {
                         const int row = rowh + 8 * i;
                         const int m = m0 + row;
-                        const float4 t0 = *(const float4*)(eb + row * EP + (lane & 7) * 8);
-                        const float4 t1 = *(const float4*)(eb + row * EP + (lane & 7) * 8 + 4);
+                        const float4 t0 = *(const float4*)(eb + row * EP + sw(row, (lane & 7) * 2));
+                        const float4 t1 = *(const float4*)(eb + row * EP + sw(row, (lane & 7) * 2 + 1));
                         float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
                         if (MODE == 2) {
                             float s1 = 0.f, s2 = 0.f;
@@ -720,6 +752,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     }
                 }
                 if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab fully read before it is overwritten
+                // PERSIST: the next tile's K-tiles 0 / 1 (requested before this epilogue) have had two slabs' time to land; the
+                // wait also covers the few stores issued so far, which drain from an empty queue -- unlike a wait at the end
+                if (PERSIST && mt == 1 && more) wait_vmcnt<0>();
             }
         };
         typedef std::integral_constant<int, 0> mode0;
@@ -743,11 +778,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             }
         }
         trace_end();
-        return;
+        if (!PERSIST || !more) return;
+        first_tile = false;
+        continue;
     }
+    if (PERSIST) return;                                             // the launcher sends only LDS-staged shapes here
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < MT; ++mt) {
-        const int m = bm + wm * WROWS + mt * 16 + fr;
+        const int m = e_bm + wm * WROWS + mt * 16 + fr;
         if (m >= m_lim) continue;
         int64_t ps_base = 0;
         if (g.ps_c2 > 0) {
@@ -757,7 +795,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int n = bn + wn * 64 + nt * 16 + fq * 4;
+            const int n = e_bn + wn * 64 + nt * 16 + fq * 4;
             if (n >= g.N) continue;
             const bool full = (n + 3 < g.N);
             float v[4];
@@ -822,6 +860,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             }
         }
     }
+    return;
+  }  // tile loop
 }
 
 }  // namespace
@@ -887,10 +927,11 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     // tuning knobs, read once per process.  A process started with CVLM_GEMM_VARIANT_LIVE=1 (tests/conftest.py,
     // tools/ab_gemm.py) re-reads them on every call so that variants can be A/B-ed and raced inside one process.
     static int group_env = env_int("CVLM_GEMM_GROUP_M", 0), tail_env = env_int("CVLM_GEMM_TAIL", 1),
-               variant_env = env_int("CVLM_GEMM_VARIANT", 0);
+               variant_env = env_int("CVLM_GEMM_VARIANT", 0), persist_env = env_int("CVLM_GEMM_PERSIST", 1);
     static const bool live_env = env_int("CVLM_GEMM_VARIANT_LIVE", 0) != 0;
     if (live_env) {
         group_env = env_int("CVLM_GEMM_GROUP_M", 0); tail_env = env_int("CVLM_GEMM_TAIL", 1); variant_env = env_int("CVLM_GEMM_VARIANT", 0);
+        persist_env = env_int("CVLM_GEMM_PERSIST", 1);
     }
 #ifdef CVLM_PROBES
     p.trace = g_trace;
@@ -898,6 +939,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (group_env < 0) group_env = 0;
     p.group_m = 8;
     p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr;
+    p.total_blocks = 0;
     const bool have_ws = g.workspace && g.workspace_bytes >= cvlm_gemm_workspace_bytes();
     hipStream_t s = (hipStream_t)stream;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
@@ -968,6 +1010,32 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
                 p.flags = (unsigned*)g.workspace;
                 p.ws = (float*)((unsigned char*)g.workspace + TAIL_FLAG_BYTES);
                 extra_blocks = rem * (S - 1);
+            }
+        }
+        // Persistent form of the 256^2 kernel: one workgroup per CU walks the tile list.  Not for launches with tail parts:
+        // their hand-off chain relies on in-order dispatch (every producer is resident or done before its consumer
+        // starts), which a persistent grid sharing the chip with another stream cannot promise.
+        const bool lds_staged = g.ps_c2 == 0 && (g.N & 7) == 0 && (g.hm_S == 0 || ((g.hm_hd & 7) == 0 && g.hm_S >= 128)) &&
+                                (g.ldo & 3) == 0 && (g.stride_o & 3) == 0 && (g.ldr & 3) == 0 && (g.stride_r & 3) == 0 &&
+                                (g.ldoh & 7) == 0 && (g.stride_oh & 7) == 0;
+        if (variant == 7 && persist_env && variant_env == 0 && lds_staged && p.a.batch == 1) {
+            static int cus_[16] = {};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            int& cus = cus_[dev & 15];
+            if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+            p.nbx = (g.N + 255) / 256; p.nby = (g.M + 255) / 256;
+            const int T = p.nbx * p.nby;
+            if (T > cus && p.tail_rem == 0) {
+                constexpr int STAGE_ = 2 * (256 + 256) * 32 * 2;
+                constexpr int smem_p = 2 * STAGE_ + 8 * 16 * 64 * 4;            // ring + one 16 x 64 f32 slab per wave = 160 KB
+                auto kp = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true>;
+                static bool attr_p[16] = {};
+                if (cvlm_first_on_device(attr_p)) (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);
+                p.total_blocks = T;
+                hipLaunchKernelGGL(kp, dim3(cus, 1), dim3(512), smem_p, s, p);
+                CVLM_CHECK_LAUNCH();
+                return 0;
             }
         }
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
