@@ -38,6 +38,64 @@ if REPO not in sys.path:
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: BF16/F16 dense ~2.5 PF
 WORK_TFLOP_PER_IMAGE = 6.461               # algorithmic work per image, text bank cached
 TOL = 1e-3                                 # BASELINE.json north_star: 1e-3 abs vs the fp32 CPU forward, IoU >= 0.999
+# Measured on this part (tools/power_roofline.py, profiles/r02_power_roofline.log): an MFMA-only loop (16x16x32 f16, random
+# operands, every CU) settles at 1.88 PF at the 1400-W socket cap (sclk 1.95 GHz of 2.4): what the matrix pipe can sustain.
+MFMA_F16_POWER_ROOFLINE_TFLOPS = 1880.0
+
+
+class PowerSampler:
+    """Socket power and shader clock during the timed region: a CHILD process polls rocm-smi (this process only reads its
+    output afterwards).  Everything is optional: no rocm-smi, no samples, no field."""
+
+    def __init__(self):
+        self.proc, self.path = None, None
+
+    def start(self):
+        import shutil, tempfile
+        if shutil.which("rocm-smi") is None:
+            return
+        fd, self.path = tempfile.mkstemp(prefix="cvlm_power_", suffix=".log")
+        os.close(fd)
+        try:
+            self.proc = subprocess.Popen(
+                ["bash", "-c", "while true; do echo STAMP $(date +%s.%N); rocm-smi --showpower --showclocks; sleep 0.25; done"],
+                stdout=open(self.path, "w"), stderr=subprocess.DEVNULL, start_new_session=True)
+        except OSError:
+            self.proc = None
+
+    def stop(self, t0: float, t1: float, device_index: int = 0):
+        import re, signal
+        if self.proc is None:
+            return None
+        try:
+            os.killpg(self.proc.pid, signal.SIGTERM)            # exactly the group started above
+            self.proc.wait(timeout=5)
+        except Exception:
+            pass
+        try:
+            with open(self.path) as f:
+                text = f.read()
+            os.unlink(self.path)
+        except OSError:
+            return None
+        pw, sc = [], []
+        for chunk in text.split("STAMP ")[1:]:
+            try:
+                ts = float(chunk.split(None, 1)[0])
+            except (ValueError, IndexError):
+                continue
+            if not (t0 <= ts <= t1):
+                continue
+            p = re.search(r"GPU\[%d\]\s*: .*Power \(W\): ([0-9.]+)" % device_index, chunk)
+            c = re.search(r"GPU\[%d\]\s*: sclk clock level: \d+: \((\d+)Mhz\)" % device_index, chunk)
+            if p and c:
+                pw.append(float(p.group(1)))
+                sc.append(int(c.group(1)))
+        if not pw:
+            return None
+        return {"socket_w_mean": round(sum(pw) / len(pw), 1), "socket_w_max": max(pw), "sclk_mhz_mean": round(sum(sc) / len(sc)),
+                "sclk_mhz_max_of_part": 2400, "samples": len(pw),
+                "note": "rocm-smi polled by a child process during the timed steps (rank 0's GPU)"}
 
 
 def parse():
@@ -194,6 +252,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    sampler = PowerSampler()
+    if rank == 0:
+        sampler.start()
+    wall0 = time.time()
     t1 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -204,6 +266,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
+    power = sampler.stop(wall0 + 0.3, time.time(), local_rank) if rank == 0 else None
     my_elapsed = elapsed
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -313,6 +376,13 @@ def main():
                     "launches": len(records), "avg_launch_us": round(1e3 * ms / len(records), 2),
                     "algorithmic_gflop_per_launch": round(flops / len(records) / 1e9, 3),
                     "gemm_share_of_step": round(ms * 1e-3 / nrep / (my_elapsed / args.steps), 3),
+                    "issued": round(achieved * cas.prec.gemm, 2),
+                    "issued_note": "MFMA flops issued: the exact mode forms every product from 3 f16 MFMAs (hi.hi + lo.hi + hi.lo)",
+                    "power_roofline": {"peak": MFMA_F16_POWER_ROOFLINE_TFLOPS, "unit": "TFLOP/s issued",
+                                       "frac_issued": round(achieved * cas.prec.gemm / MFMA_F16_POWER_ROOFLINE_TFLOPS, 4),
+                                       "note": "what an MFMA-only loop sustains at the 1400-W socket cap with random operands "
+                                               "(profiles/r02_power_roofline.log); the GEMM itself runs AT the cap: its energy per "
+                                               "launch = matrix pipe 51 % + L2->LDS DMA 26 % + idle 21 % (DESIGN.md section 6)"},
                     "secondary": secondary}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N = 1)
@@ -371,7 +441,7 @@ def main():
                         "note": "per-step HIP-event durations of the timed steps on rank 0"},
             "images_per_s_per_gpu": round(value / world, 3),
             "achieved_tflops_algorithmic": round(value * WORK_TFLOP_PER_IMAGE, 1) if args.geometry == "demo" else None,
-            "parity": parity, "bank_check": bank_check,
+            "parity": parity, "bank_check": bank_check, "power": power,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

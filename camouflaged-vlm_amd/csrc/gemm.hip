@@ -1046,6 +1046,8 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #endif
 #ifdef CVLM_PROBES   /* make EXTRA=-DCVLM_PROBES: the variants behind profiles/r01_gemm_probes.md and tools/{ab,trace}_gemm.py */
         else if (variant == 4 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 0, 4);
+        else if (variant == 24 && (g.K % 64) == 0) CVLM_LAUNCH_D(3, 2, 2, 2, 64, 2, 4);   /* probe: DMA only, 128-byte rows (full L2 lines) */
+        else if (variant == 21) CVLM_LAUNCH_D(3, 2, 2, 2, 32, 2, 4);                      /* probe: DMA only, 64-byte rows, same tile */
         else if (variant == 5) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 0, 8);          /* 256x256, 8 waves of 128x64 */
         else if (variant == 6) CVLM_LAUNCH_D(3, 2, 4, 4, 32, 0, 8);          /* same tile, mid-tile slot recycling */
         else if (variant == 8) CVLM_LAUNCH_D(3, 2, 2, 6, 32, 0, 8);          /* 256x128, 4 waves, one recycled slot, 2 WG/CU */
