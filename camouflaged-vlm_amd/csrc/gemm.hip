@@ -1018,7 +1018,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         const bool lds_staged = g.ps_c2 == 0 && (g.N & 7) == 0 && (g.hm_S == 0 || ((g.hm_hd & 7) == 0 && g.hm_S >= 128)) &&
                                 (g.ldo & 3) == 0 && (g.stride_o & 3) == 0 && (g.ldr & 3) == 0 && (g.stride_r & 3) == 0 &&
                                 (g.ldoh & 7) == 0 && (g.stride_oh & 7) == 0;
-        if (variant == 7 && persist_env && variant_env == 0 && lds_staged && p.a.batch == 1) {
+        if (variant == 7 && persist_env && (variant_env == 0 || variant_env == 7) && lds_staged && p.a.batch == 1) {
             static int cus_[16] = {};
             int dev = 0;
             (void)hipGetDevice(&dev);

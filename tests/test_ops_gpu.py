@@ -174,6 +174,58 @@ def test_gemm_layernorm_fold_and_h2_residual(hip, M, D, N, act):
     assert float(((st2.cpu().double() - s_ref).abs() / s_mag).max()) < 2e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["h2", "f32_residual", "head_major", "ln_fold_gelu", "h2_residual_stats"])
+def test_gemm_persistent_equals_plain(hip, form, monkeypatch):
+    """The persistent form of the 256^2 kernel (more tiles than CUs, no tail parts; CVLM_GEMM_PERSIST, default on) gives
+    bit-identical outputs to one-workgroup-per-tile launches in every LDS-staged epilogue form, ragged last tiles included."""
+    monkeypatch.setenv("CVLM_GEMM_TAIL", "0")
+    monkeypatch.setenv("CVLM_GEMM_VARIANT", "7")                       # the 256^2 kernel whatever the tile model prefers
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(5)
+    rn = lambda *sh, scale=1.0: torch.randn(*sh, device=dev, generator=g) * scale
+    if form == "head_major":
+        Bn, S, Hh, hd = 9, 1024, 8, 80                                 # M = 9216, N = 1920: 36 x 8 = 288 tiles
+        M, N, K = Bn * S, 3 * Hh * hd, 96
+    else:
+        M, N, K = 4648 + 8, 4096 - 8, 128                              # 19 x 16 = 304 tiles, ragged in M and N
+    A = hip.H2(rn(2, M, K).half() * torch.tensor([1.0, 2.0 ** -11], device=dev).view(2, 1, 1).half())
+    W = hip.H2(rn(2, N, K, scale=0.1).half() * torch.tensor([1.0, 2.0 ** -11], device=dev).view(2, 1, 1).half())
+    bias = rn(N)
+    res, cs = rn(M, N), rn(N)
+    st_in = torch.stack([rn(M) * 3.0, 40.0 + rn(M).abs() * 10.0], 1).contiguous()
+    x_in = rn(2, M, N).half() * torch.tensor([1.0, 2.0 ** -11], device=dev).view(2, 1, 1).half()
+    outs = {}
+    for persist in ("0", "1"):
+        monkeypatch.setenv("CVLM_GEMM_PERSIST", persist)
+        kw = {}
+        if form == "h2":
+            o = hip.H2.empty(M, N); o.t.fill_(float("nan")); kw = dict(out_h2=o, act=1)
+        elif form == "f32_residual":
+            o = torch.full((M, N), float("nan"), device=dev); kw = dict(out_f32=o, residual=res)
+        elif form == "head_major":
+            o = hip.H2.empty(M, N); o.t.fill_(float("nan")); kw = dict(out_h2=o, head_major=(S, Hh, hd))
+        elif form == "ln_fold_gelu":
+            o = hip.H2.empty(M, N); o.t.fill_(float("nan"))
+            kw = dict(out_h2=o, act=1, ln_fold=(st_in, cs, 1e-6, K), out_scale=0.25)
+        else:
+            xh = hip.H2(x_in.clone())
+            o = hip.H2.empty(M, N); o.t.fill_(float("nan"))
+            st = torch.zeros(M, 2, device=dev)
+            kw = dict(out_h2=o, residual_h2=(xh, 4.0), out_scale=0.25, row_stats=st)
+        torch.manual_seed(0)
+        hip.gemm(A, W, M, N, K, bias=bias, workspace=hip.new_gemm_workspace(dev), **kw)
+        torch.cuda.synchronize()
+        outs[persist] = (o.t.clone() if isinstance(o, hip.H2) else o.clone(), kw.get("row_stats"))
+    a, b = outs["0"][0], outs["1"][0]
+    assert bool(torch.isfinite(a.float()).all())
+    assert torch.equal(a, b)
+    if form == "h2_residual_stats":                                    # fp32 atomics: same sums up to the order of the 8-column pieces
+        s0, s1 = outs["0"][1], outs["1"][1]
+        mag = torch.stack([(s0[:, 1] * N).sqrt(), s0[:, 1]], 1)          # sum |x| <= sqrt(N * sum x^2)
+        assert float(((s0 - s1).abs() / mag).max()) < 1e-6
+
+
 def to_head_major(qkv, Bn, S, Hh, hd):
     """[B*S][3][H][hd] -> [3][B][H][S][hd] flattened back to the same (B*S, 3*H*hd) buffer shape."""
     return qkv.reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).contiguous().reshape(Bn * S, 3 * Hh * hd)
