@@ -970,7 +970,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
                 if (S >= 2) tail = tail_us(S, g.K, rem);
             }
             const double m7 = (double)(t5 / 256) * tile + tail;
-            variant = (m7 <= m1 && m7 <= m2) ? 5 : (m2 <= m1 ? 2 : 1);
+            // a near tie goes to the 256^2 tile: it moves a third fewer L2->LDS bytes per flop, and at the power cap the
+            // joules count (proj 32768 x 1280 x 1280 is modelled 305 vs 300 us; with 256^2 tiles the cascade gains 0.85 %)
+            variant = (m7 <= 1.04 * m1 && m7 <= 1.04 * m2) ? 5 : (m2 <= m1 ? 2 : 1);
         } else if (t5 >= 200 && t5 <= 256) variant = 5;                          // one full wave of 256^2 tiles
         else if (t5 >= 1536) {
             const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / 1.08;
