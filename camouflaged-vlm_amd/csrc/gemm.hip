@@ -50,7 +50,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // PERSIST (256^2 staggered kernel, no tail parts): one workgroup per CU walks the tile list; the first K-tile of the
 // next tile is requested before the epilogue of the current one, so the tile prologue (address set-up + first DMA latency,
 // ~4 us of a ~110 us K = 1280 tile) runs under the epilogue's stores.  The epilogue stages through LDS behind slot 0.
-template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false>
+// EPI >= 0 (256^2 kernel): only epilogue form EPI of the LDS-staged path is compiled in (0 plain, 1 LayerNorm fold, 2 h2
+// residual + row statistics) -- one function with all three let the register needs of one form decide the allocation of
+// the others (batched statistics in form 2 cost the fold-form launches 4 %).  -1: run-time dispatch, every form.
+template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
     static_assert(!PERSIST || NSTAGE == 5, "persistent form exists for the staggered 256^2 loop only");
     constexpr int WROWS = MT * 16;                                  // activation rows per wave
@@ -642,10 +645,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         ln_c[mt][i] = mu * rs;
                     }
             }
+            // MODE 2: the residual planes of slab mt + 1 are requested before slab mt is staged -- asked for where they are
+            // used, each of the 16 row pieces of a wave waited out a full HBM/L2 latency (proj 286 -> 358 us)
+            float ps1[8], ps2[8];                                     // MODE 2: row sums of the last four slabs (8 row pieces per lane group)
+            half8 res_h[2][2], res_l[2][2];
+            auto load_res = [&](int mt_, int buf) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int m = mw + mt_ * 16 + rowh + 8 * i;
+                    m = m < g.M ? m : g.M - 1;                        // clamped, always a valid address: masked at the use
+                    const int64_t ro = (int64_t)m * g.ldrh + (nh < g.N ? nh : 0);
+                    res_h[buf][i] = *(const half8*)((const half_t*)g.res_hi + ro);
+                    res_l[buf][i] = *(const half8*)((const half_t*)g.res_lo + ro);
+                }
+            };
+            const bool have_res = MODE == 2 && g.res_hi != nullptr;
+            if (have_res) load_res(0, 0);
             if (DBG == 4) { asm volatile("" ::"v"(bv[0][0]), "v"(bv[3][3])); tr3 = wall_clock64(); }
 #pragma clang loop unroll(full)
             for (int mt = 0; mt < MT; ++mt) {
                 if (DBG == 4 && mt == 1) tr4 = wall_clock64();
+                if (have_res && mt + 1 < MT) load_res(mt + 1, (mt + 1) & 1);
                 float* eb = ebuf + (NBUF == 2 ? (mt & 1) * (16 * EP) : 0);
                 const int m0 = mw + mt * 16;
 #pragma unroll
@@ -688,24 +708,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         if (MODE == 2) {
                             float s1 = 0.f, s2 = 0.f;
                             if (m < m_lim && nh < g.N) {
-                                if (g.res_hi) {
-                                    const int64_t ro = (int64_t)m * g.ldrh + nh;
-                                    const half8 rh = *(const half8*)((const half_t*)g.res_hi + ro);
-                                    const half8 rl = *(const half8*)((const half_t*)g.res_lo + ro);
+                                if (have_res) {
+                                    const half8 rh = res_h[mt & 1][i], rl = res_l[mt & 1][i];
 #pragma unroll
                                     for (int j = 0; j < 8; ++j) v[j] += ((float)rh[j] + (float)rl[j]) * g.res_scale;
                                 }
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 += v[j] * v[j]; }
                             }
-                            if (g.row_stats) {                             // the 8 lanes of a row: three exchange steps, one atomic pair
+                            if (g.row_stats) {                             // the 8 lanes of a row: three exchange steps, every lane ends with the sums
                                 s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
                                 s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
                                 s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
-                                if ((lane & 7) == 0 && m < m_lim) {
-                                    atomicAdd(g.row_stats + 2 * (int64_t)m, s1);
-                                    atomicAdd(g.row_stats + 2 * (int64_t)m + 1, s2);
-                                }
+                                ps1[(mt & 3) * 2 + i] = s1; ps2[(mt & 3) * 2 + i] = s2;
                             }
                         }
                         if (MODE == 1) {
@@ -751,6 +766,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         }
                     }
                 }
+                if (MODE == 2 && (mt & 3) == 3 && g.row_stats) {
+                    // Float atomics execute at the memory side, one wave-instruction per ~50 ns per CU whatever the number of
+                    // active lanes (MI355X_MICROARCH.md): one pair per row piece (8 active lanes, 32 instructions per wave
+                    // and tile) cost 12.8 us of a ~110-us tile.  Here the 64 row pieces of four slabs go out as ONE pair
+                    // with all lanes active: lane (r, q) adds row piece q of row group r.
+                    const int q = lane & 7;
+                    float a1 = ps1[0], a2 = ps2[0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) { a1 = (q == k) ? ps1[k] : a1; a2 = (q == k) ? ps2[k] : a2; }
+                    const int m = mw + (mt - 3 + (q >> 1)) * 16 + rowh + 8 * (q & 1);
+                    if (m < m_lim) {
+                        atomicAdd(g.row_stats + 2 * (int64_t)m, a1);
+                        atomicAdd(g.row_stats + 2 * (int64_t)m + 1, a2);
+                    }
+                }
                 if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab fully read before it is overwritten
                 // PERSIST: the next tile's K-tiles 0 / 1 (requested before this epilogue) have had two slabs' time to land; the
                 // wait also covers the few stores issued so far, which drain from an empty queue -- unlike a wait at the end
@@ -760,13 +790,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         typedef std::integral_constant<int, 0> mode0;
         typedef std::integral_constant<int, 1> mode1;
         typedef std::integral_constant<int, 2> mode2;
-        if (g.ln_stats) {                                                // launcher: out_hi only, act in {none, GELU, QuickGELU}
+        if (EPI == -1 ? g.ln_stats != nullptr : EPI == 1) {              // launcher: out_hi only, act in {none, GELU, QuickGELU}
             switch (g.act) {
                 case ACT_GELU: fast_epi(std::integral_constant<int, ACT_GELU>{}, mode1{}); break;
                 case ACT_QUICKGELU: fast_epi(std::integral_constant<int, ACT_QUICKGELU>{}, mode1{}); break;
                 default: fast_epi(std::integral_constant<int, ACT_NONE>{}, mode1{}); break;
             }
-        } else if (g.res_hi || g.row_stats) {                            // launcher: out_hi only, act none
+        } else if (EPI == -1 ? (g.res_hi || g.row_stats) : EPI == 2) {   // launcher: out_hi only, act none
             fast_epi(std::integral_constant<int, ACT_NONE>{}, mode2{});
         } else {
             switch (g.act) {
@@ -782,7 +812,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         first_tile = false;
         continue;
     }
-    if (PERSIST) return;                                             // the launcher sends only LDS-staged shapes here
+    if (PERSIST || EPI >= 0) return;                                 // the launcher sends only LDS-staged shapes here
 #pragma clang loop unroll(full)
     for (int mt = 0; mt < MT; ++mt) {
         const int m = e_bm + wm * WROWS + mt * 16 + fr;
@@ -996,6 +1026,16 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_); \
         hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby + extra_blocks, p.a.batch), dim3(WM* WN * 64), smem_, s, p); \
     } while (0)
+#define CVLM_LAUNCH_E(EPI_)                                                                                        \
+    do {                                                                                                           \
+        constexpr int smem_ = 2 * 2 * (256 + 256) * 32 * 2;                                                        \
+        p.nbx = (g.N + 255) / 256; p.nby = (g.M + 255) / 256;                                                      \
+        auto kern_ = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, false, EPI_>;                                            \
+        static bool attr_[16] = {};                                                                                \
+        if (cvlm_first_on_device(attr_))                                                                           \
+            (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);     \
+        hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby + extra_blocks, 1), dim3(512), smem_, s, p);                   \
+    } while (0)
     int extra_blocks = 0;
     if (g.split == 3) {
         if (variant == 5 && variant_env == 0) variant = 7;      // auto: staggered wave groups (3-5 % over the plain 256^2 loop)
@@ -1031,17 +1071,26 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             if (T > cus && p.tail_rem == 0) {
                 constexpr int STAGE_ = 2 * (256 + 256) * 32 * 2;
                 constexpr int smem_p = 2 * STAGE_ + 8 * 16 * 64 * 4;            // ring + one 16 x 64 f32 slab per wave = 160 KB
-                auto kp = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true>;
-                static bool attr_p[16] = {};
-                if (cvlm_first_on_device(attr_p)) (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);
                 p.total_blocks = T;
-                hipLaunchKernelGGL(kp, dim3(cus, 1), dim3(512), smem_p, s, p);
+#define CVLM_LAUNCH_P(EPI_)                                                                                        \
+    do {                                                                                                           \
+        auto kp = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true, EPI_>;                                                \
+        static bool attr_p[16] = {};                                                                               \
+        if (cvlm_first_on_device(attr_p))                                                                          \
+            (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);       \
+        hipLaunchKernelGGL(kp, dim3(cus, 1), dim3(512), smem_p, s, p);                                             \
+    } while (0)
+                if (fold) CVLM_LAUNCH_P(1); else if (h2res) CVLM_LAUNCH_P(2); else CVLM_LAUNCH_P(0);
+#undef CVLM_LAUNCH_P
                 CVLM_CHECK_LAUNCH();
                 return 0;
             }
         }
         if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
-        else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* 256x256, 8 waves, wave groups staggered */
+        else if (variant == 7 && lds_staged && p.a.batch == 1) {             /* 256x256, 8 waves, wave groups staggered; one epilogue form */
+            if (fold) CVLM_LAUNCH_E(1); else if (h2res) CVLM_LAUNCH_E(2); else CVLM_LAUNCH_E(0);
+        }
+        else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* same, every epilogue form (pixel shuffle, odd N, batched) */
 #ifdef CVLM_PROBES
         else if (variant == 77) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 7, 8);        /* probe: s_setprio around MFMA groups */
         else if (variant == 87) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 8, 8);        /* probe: static priority for waves 4..7 */
@@ -1080,6 +1129,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     }
 #undef CVLM_LAUNCH
 #undef CVLM_LAUNCH_D
+#undef CVLM_LAUNCH_E
     CVLM_CHECK_LAUNCH();
     return 0;
 }
