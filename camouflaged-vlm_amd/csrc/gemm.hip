@@ -29,6 +29,9 @@ constexpr int BK_MIN = 32;
 // chunk permutation g(q), q = (row >> 2) & 3 (derived for the ds_read_b128 lane groups)
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
 
+// 16 zero bytes: what the DMA of an implicit 3x3 convolution reads for a tap that falls outside the image
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
 struct GemmParams {
     cvlm_gemm_args a;
     int nbx, nby;
@@ -53,9 +56,13 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // EPI >= 0 (256^2 kernel): only epilogue form EPI of the LDS-staged path is compiled in (0 plain, 1 LayerNorm fold, 2 h2
 // residual + row statistics) -- one function with all three let the register needs of one form decide the allocation of
 // the others (batched statistics in form 2 cost the fold-form launches 4 %).  -1: run-time dispatch, every form.
-template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1>
+// CONV (2-stage loop): A is an NHWC image (conv_h x conv_w x conv_c per batch item, lda = conv_c) and the K axis runs
+// over the 9 taps of a 3x3 / pad 1 / stride 1 convolution, k = (ky*3 + kx)*C + c: the gather of im2col happens in the
+// DMA source addresses (a tap outside the image reads 16 zero bytes), nothing is materialised.
+template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1, bool CONV = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
     static_assert(!PERSIST || NSTAGE == 5, "persistent form exists for the staggered 256^2 loop only");
+    static_assert(!CONV || (NSTAGE == 2 && BK == 32), "implicit 3x3 convolution: 2-stage loop, 32-wide K-tiles");
     constexpr int WROWS = MT * 16;                                  // activation rows per wave
     constexpr int BM = WM * WROWS, BN = WN * 64, NWAVE = WM * WN;
     constexpr int NPA = (SPLIT == 3) ? 2 : 1;                       // planes per operand
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     int bm = 0, bn = 0, kpart = 0, kparts = 1, tail_j = 0, nk = 0;
     const half_t* src[PER_WAVE];
     int dst_off[PER_WAVE];                                            // stage layout: [Ahi][Alo][Whi][Wlo]; instruction i covers 16 rows x 64 B
+    [[maybe_unused]] int tapmask[PER_WAVE];                           // CONV: bit t = tap t of this lane's row lies inside the image; bit 9 = weight row
     // Everything a run-time ?: selects between comes in as a parameter or is a local of the body: a conditional between two
     // by-reference captures becomes a run-time index into the closure, which pins it -- and every capture -- in scratch.
     auto set_tile_ = [&](int pid, const half_t* ahi, const half_t* alo, const half_t* whi, const half_t* wlo,
@@ -138,6 +146,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             grow = grow < lim ? grow : lim;
             src[j] = base + (int64_t)grow * ld + chunk * 8;
             dst_off[j] = (isW ? NPA * A_PLANE + plane * W_PLANE : plane * A_PLANE) + sub * 1024;
+            if (CONV) {
+                const int px = grow % g.conv_w, py = (grow / g.conv_w) % g.conv_h;
+                int mk = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+                    mk |= (yy >= 0 && yy < g.conv_h && xx >= 0 && xx < g.conv_w) ? (1 << t) : 0;
+                }
+                tapmask[j] = isW ? 512 : mk;
+            }
         }
         nk = g.K / BK;
         if (NSTAGE == 5 && kparts > 1) {                                 // this workgroup's share of the K-tiles
@@ -161,10 +179,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     };
 
     floatx4 acc[MT][4];
+    // DMA source of staging instruction j for K-tile t.  CONV: K-tile t lies in tap t / (C / 32) (C a power of two), channels
+    // from (t % (C / 32)) * 32; the tap moves the pixel by (dy, dx), i.e. the address by a wave-uniform offset.
+    const int conv_lc = CONV ? 31 - __builtin_clz((unsigned)(g.conv_c / BK)) : 0;
+    auto src_at = [&](int j, int t) -> const void* {
+        if (!CONV) return src[j] + (int64_t)t * BK;
+        const int tap = t >> conv_lc, c0 = (t - (tap << conv_lc)) * BK;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                            // tap / 3, tap % 3 for tap in 0..8
+        const int64_t off = (int64_t)((ky - 1) * g.conv_w + (kx - 1)) * g.conv_c + c0;
+        const half_t* inside = src[j] + off;
+        const half_t* plain = src[j] + (int64_t)t * BK;
+        const void* a = ((tapmask[j] >> tap) & 1) ? (const void*)inside : (const void*)&g_zero16;
+        return (tapmask[j] & 512) ? (const void*)plain : a;
+    };
     auto issue = [&](int t, int slot) {
         if (DBG == 1 && t > 1) return;                       // timing probe: no DMA in the steady state
 #pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) glds16(src[j] + (int64_t)t * BK, smem + slot * STAGE + dst_off[j]);
+        for (int j = 0; j < PER_WAVE; ++j) glds16(src_at(j, t), smem + slot * STAGE + dst_off[j]);
     };
     // One K-tile of MFMAs from `slot`; the DMA of K-tile `tn` into `sn` (tn < 0: none) is issued in pieces
     // between the MFMA groups so the load issue (readfirstlane + m0 + TA acceptance, ~100 cycles each)
@@ -181,7 +212,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         const unsigned char* pWhi = cur + NPA * A_PLANE;
         const unsigned char* pWlo = pWhi + W_PLANE;
         const bool dma = tn >= 0 && !(DBG == 1 && tn > 1);
-        const int64_t koff = (int64_t)tn * BK;
         unsigned char* nxt = smem + sn * STAGE;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
@@ -219,7 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     const int j0 = (g0 * PER_WAVE) / NGI, j1 = (g1 * PER_WAVE) / NGI;
                     if (dma) {
 #pragma unroll
-                        for (int j = j0; j < j1; ++j) glds16(src[j] + koff, nxt + dst_off[j]);
+                        for (int j = j0; j < j1; ++j) glds16(src_at(j, tn), nxt + dst_off[j]);
                     }
                 }
             }
@@ -941,6 +971,13 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (!g.out_f32 && !g.out_hi) return CVLM_E_BADARG;
     if (g.ps_c2 > 0 && ((g.ps_c2 & 3) || g.ps_h <= 0 || g.ps_w <= 0)) return CVLM_E_BADARG;
     if (g.hm_S > 0 && ((g.hm_hd & 3) || g.hm_H <= 0 || (g.M % g.hm_S) || g.N != 3 * g.hm_H * g.hm_hd || !g.out_hi)) return CVLM_E_BADARG;
+    const bool conv = g.conv_c > 0;
+    if (conv) {
+        // implicit 3x3 convolution: channels a power of two >= 32 (a K-tile never straddles a tap), rows = whole images
+        if (g.conv_h <= 0 || g.conv_w <= 0 || g.conv_c < 32 || (g.conv_c & (g.conv_c - 1)) || g.K != 9 * g.conv_c ||
+            g.lda != g.conv_c || (g.M % (g.conv_h * g.conv_w)) || g.batch > 1)
+            return CVLM_E_UNSUPPORTED;
+    }
     const bool fold = g.ln_stats != nullptr, h2res = g.res_hi != nullptr || g.row_stats != nullptr;
     if (fold || h2res) {
         // these two epilogue forms exist on the LDS-staged path only: h2 output, 8-column row pieces, one problem per launch
@@ -1037,6 +1074,20 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby + extra_blocks, 1), dim3(512), smem_, s, p);                   \
     } while (0)
     int extra_blocks = 0;
+    if (conv) {
+        // 256 x 64 tiles (4 waves, 2 workgroups per CU): the edge head's N is 32 / 64, the neck's 256
+        constexpr int smem_c = 2 * 2 * (256 + 64) * 32 * 2;
+        p.nbx = (g.N + 63) / 64; p.nby = (g.M + 255) / 256;
+        static bool attr_c[16] = {};
+        if (cvlm_first_on_device(attr_c)) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<3, 4, 1, 2, 32, 0, 4, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_c);
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<1, 4, 1, 2, 32, 0, 4, false, -1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_c);
+        }
+        if (g.split == 3) hipLaunchKernelGGL((gemm_nt_kernel<3, 4, 1, 2, 32, 0, 4, false, -1, true>), dim3(p.nbx * p.nby, 1), dim3(256), smem_c, s, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<1, 4, 1, 2, 32, 0, 4, false, -1, true>), dim3(p.nbx * p.nby, 1), dim3(256), smem_c, s, p);
+        CVLM_CHECK_LAUNCH();
+        return 0;
+    }
     if (g.split == 3) {
         if (variant == 5 && variant_env == 0) variant = 7;      // auto: staggered wave groups (3-5 % over the plain 256^2 loop)
         // tile rows per L2 super-tile: 8 for the small tiles; the 256^2 kernel is 2-3 % faster with 4 (2 at long K),

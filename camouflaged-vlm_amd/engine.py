@@ -126,6 +126,13 @@ class LnLinear(Linear):
         self.colsum = (self.w.t.double().sum(0).sum(1) * self.alpha).float().contiguous()
 
 
+def implicit_conv_ok(C: int) -> bool:
+    """cvlm_gemm's implicit 3x3 convolution wants a power-of-two channel count >= 32 (include/cvlm.h, ABI 4); the tiny test
+    geometries fall back to cvlm_im2col3x3 + GEMM.  CVLM_IMPLICIT_CONV=0 forces the fallback (A/B, tests)."""
+    import os
+    return C >= 32 and (C & (C - 1)) == 0 and os.environ.get("CVLM_IMPLICIT_CONV", "1") == "1"
+
+
 class _Base:
     def __init__(self, device, precision: Precision):
         self.device = device
@@ -356,11 +363,16 @@ class SamEncoder(_Base):
         C = g.out_chans
         c1 = ws.f32("neck_c1", M, C)
         self.gemm(xn, self.neck0, M, out_f32=c1, alpha=1.0 / X_SCALE)
-        hip.layernorm(c1, self.nk1[0], self.nk1[1], 1e-6, M, C, out_f32=c1)
-        col = ws.h2("neck_col", M, 9 * C)
-        hip.im2col3x3(c1, B, G, G, C, col)
         feats = ws.f32(getattr(self, "_out_name", "features"), M, C)
-        self.gemm(col, self.neck2, M, out_f32=feats)
+        if implicit_conv_ok(C):                                      # 3x3 as an implicit GEMM: nothing materialised
+            c1h = ws.h2("neck_c1h", M, C)
+            hip.layernorm(c1, self.nk1[0], self.nk1[1], 1e-6, M, C, out_h2=c1h)
+            self.gemm(c1h, self.neck2, M, out_f32=feats, conv3x3=(G, G, C))
+        else:
+            hip.layernorm(c1, self.nk1[0], self.nk1[1], 1e-6, M, C, out_f32=c1)
+            col = ws.h2("neck_col", M, 9 * C)
+            hip.im2col3x3(c1, B, G, G, C, col)
+            self.gemm(col, self.neck2, M, out_f32=feats)
         hip.layernorm(feats, self.nk3[0], self.nk3[1], 1e-6, M, C, out_f32=feats)
         return feats
 
@@ -403,8 +415,9 @@ class MaskDecoder(_Base):
         self.mf = (convT3("embedding_maskfeature.0"), convT3("embedding_maskfeature.3"))
         self.pe: Optional[torch.Tensor] = None
 
-    def _upscale(self, x_h2: H2, B: int, G: int, name: str, final_gelu: bool, out: torch.Tensor) -> torch.Tensor:
-        """mask_decoder_edge.py:53-59 / 82-87 on token-major input [B*G*G][C]."""
+    def _upscale(self, x_h2: H2, B: int, G: int, name: str, final_gelu: bool, out: torch.Tensor,
+                 out_h2: Optional[H2] = None) -> torch.Tensor:
+        """mask_decoder_edge.py:53-59 / 82-87 on token-major input [B*G*G][C]; out_h2: the same values as h2 planes too."""
         C, ws = self.g.prompt_embed_dim, self.ws
         l0, l3 = self.up[name]
         u1 = ws.f32(name + "_u1", B * 4 * G * G, C // 4)
@@ -412,8 +425,9 @@ class MaskDecoder(_Base):
         u1h = ws.h2(name + "_u1h", B * 4 * G * G, C // 4)
         w, b = self.ln[name + ".1"]
         hip.layernorm(u1, w, b, 1e-6, B * 4 * G * G, C // 4, act=ACT_GELU, out_h2=u1h)
+        kw = dict(out_h2=out_h2) if out_h2 is not None else {}
         self.gemm(u1h, l3, B * 4 * G * G, out_f32=out, pixel_shuffle=(2 * G, 2 * G, 2 * (C // 8)),
-                  act=ACT_GELU if final_gelu else ACT_NONE)
+                  act=ACT_GELU if final_gelu else ACT_NONE, **kw)
         return out
 
     def _attn(self, name: str, q: H2, k: H2, v: H2, B: int, nq: int, nk: int, out: torch.Tensor) -> None:
@@ -502,17 +516,25 @@ class MaskDecoder(_Base):
         hip.layernorm(queries, *self.ln["transformer.norm_final_attn"], 1e-5, B * NT, C, add=ao_q, add_rows=B * NT,
                       out_f32=hs)
         # :167-170 upscaling + edge feature head
-        up = self._upscale(vh, B, G, "output_upscaling", True, ws.f32("upscaled", B * 16 * T, C // 8))
         HW = 16 * T
-        col1 = ws.h2("mf_col1", B * HW, 9 * (C // 8))
-        hip.im2col3x3(up, B, 4 * G, 4 * G, C // 8, col1)
         m1 = ws.f32("mf_1", B * HW, C // 4)
-        self.gemm(col1, self.mf[0], B * HW, out_f32=m1)
-        hip.layernorm(m1, *self.ln["embedding_maskfeature.1"], 1e-6, B * HW, C // 4, act=ACT_GELU, out_f32=m1)
-        col2 = ws.h2("mf_col2", B * HW, 9 * (C // 4))
-        hip.im2col3x3(m1, B, 4 * G, 4 * G, C // 4, col2)
         edge_emb = ws.f32("edge_emb", B * HW, C // 8)
-        self.gemm(col2, self.mf[1], B * HW, residual=edge_feat, out_f32=edge_emb)
+        if implicit_conv_ok(C // 8):                                 # both 3x3 convolutions as implicit GEMMs
+            up_h = ws.h2("upscaled_h", B * HW, C // 8)
+            up = self._upscale(vh, B, G, "output_upscaling", True, ws.f32("upscaled", B * HW, C // 8), out_h2=up_h)
+            self.gemm(up_h, self.mf[0], B * HW, out_f32=m1, conv3x3=(4 * G, 4 * G, C // 8))
+            m1h = ws.h2("mf_1h", B * HW, C // 4)
+            hip.layernorm(m1, *self.ln["embedding_maskfeature.1"], 1e-6, B * HW, C // 4, act=ACT_GELU, out_h2=m1h)
+            self.gemm(m1h, self.mf[1], B * HW, residual=edge_feat, out_f32=edge_emb, conv3x3=(4 * G, 4 * G, C // 4))
+        else:
+            up = self._upscale(vh, B, G, "output_upscaling", True, ws.f32("upscaled", B * HW, C // 8))
+            col1 = ws.h2("mf_col1", B * HW, 9 * (C // 8))
+            hip.im2col3x3(up, B, 4 * G, 4 * G, C // 8, col1)
+            self.gemm(col1, self.mf[0], B * HW, out_f32=m1)
+            hip.layernorm(m1, *self.ln["embedding_maskfeature.1"], 1e-6, B * HW, C // 4, act=ACT_GELU, out_f32=m1)
+            col2 = ws.h2("mf_col2", B * HW, 9 * (C // 4))
+            hip.im2col3x3(m1, B, 4 * G, 4 * G, C // 4, col2)
+            self.gemm(col2, self.mf[1], B * HW, residual=edge_feat, out_f32=edge_emb)
         # :172-186 hyper-network rows actually used: mask token 0 (hs row 1) and edge token (hs row 5)
         hyper = ws.f32("hyper", B, 5, C // 8)
         row, rowh = ws.f32("h_row", B, C), ws.h2("h_rowh", B, C)

@@ -25,7 +25,7 @@ EXPORTS = [
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GemmArgs(C.Structure):
@@ -44,6 +44,7 @@ class GemmArgs(C.Structure):
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_D", C.c_int32),
         ("res_hi", C.c_void_p), ("res_lo", C.c_void_p), ("ldrh", C.c_int64), ("res_scale", C.c_float),
         ("row_stats", C.c_void_p),
+        ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_c", C.c_int32),
     ]
 
 
@@ -172,8 +173,10 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          workspace: Optional[torch.Tensor] = None,
          ln_fold: Optional[Tuple[torch.Tensor, torch.Tensor, float, int]] = None,
          residual_h2: Optional[Tuple["H2", float]] = None, ldrh: Optional[int] = None,
-         row_stats: Optional[torch.Tensor] = None) -> None:
-    """ln_fold = (stats [M][2] f32, colsum [N] f32, eps, D): LayerNorm of the input folded into this GEMM (include/cvlm.h);
+         row_stats: Optional[torch.Tensor] = None, conv3x3: Optional[Tuple[int, int, int]] = None) -> None:
+    """conv3x3 = (H, W, C): `a` is an NHWC image [B*H*W][C] and K = 9*C runs over the taps of a 3x3 / pad 1 convolution
+    (implicit GEMM: the im2col gather happens in the DMA addresses).
+    ln_fold = (stats [M][2] f32, colsum [N] f32, eps, D): LayerNorm of the input folded into this GEMM (include/cvlm.h);
     residual_h2 = (x h2, scale): residual given as h2 planes; row_stats [M][2] f32: += (sum, sum of squares) of the result rows."""
     _on_current_device(a.t)
     g = GemmArgs()
@@ -199,6 +202,9 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
         g.res_hi, g.res_lo, g.ldrh, g.res_scale = r.hi.data_ptr(), r.lo.data_ptr(), (ldrh if ldrh is not None else N), rs
     if row_stats is not None:
         g.row_stats = row_stats.data_ptr()
+    if conv3x3 is not None:
+        g.conv_h, g.conv_w, g.conv_c = conv3x3
+        g.lda = conv3x3[2]
     if workspace is not None:
         g.workspace, g.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     _check(load().cvlm_gemm(C.byref(g), C.c_void_p(_stream())), "cvlm_gemm")

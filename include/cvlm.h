@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 3
+#define CVLM_ABI_VERSION 4
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -84,6 +84,12 @@ typedef struct cvlm_gemm_args {
      * GEMMs of a transformer block with no separate LayerNorm pass. */
     const void* res_hi; const void* res_lo; int64_t ldrh; float res_scale;
     float* row_stats;
+    /* ABI 4 -- implicit 3x3 / pad 1 / stride 1 convolution (conv_c > 0): A is an NHWC image in h2 planes, rows m = (b, y, x)
+     * on a conv_h x conv_w grid with conv_c channels (lda = conv_c), and K = 9 * conv_c runs over the taps,
+     * k = (ky*3 + kx)*conv_c + c -- the layout cvlm_im2col3x3 materialises; here the gather happens in the DMA source
+     * addresses and a tap outside the image reads zeros.  conv_c a power of two >= 32, one problem per launch.
+     * Replaces the 3x3 convolutions of image_encoder.py:150 (neck) and mask_decoder_edge.py:88-93 (edge feature head). */
+    int32_t conv_h, conv_w, conv_c;
 } cvlm_gemm_args;
 int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
 int64_t cvlm_gemm_workspace_bytes(void);

@@ -226,6 +226,28 @@ def test_gemm_persistent_equals_plain(hip, form, monkeypatch):
         assert float(((s0 - s1).abs() / mag).max()) < 1e-6
 
 
+@pytest.mark.parametrize("Bn,H,W,Cc,N", [(2, 20, 24, 32, 64), (1, 64, 64, 256, 256), (3, 9, 7, 64, 32)])
+def test_gemm_implicit_conv3x3(hip, Bn, H, W, Cc, N):
+    """conv3x3 = (H, W, C) on the NHWC image == cvlm_im2col3x3 + plain GEMM (same K order: bit-identical), and both match
+    torch's conv2d on the fp64 values of the h2 operands (image_encoder.py:150, mask_decoder_edge.py:88-93)."""
+    M, K = Bn * H * W, 9 * Cc
+    x = rnd(M, Cc, seed=91)
+    w = rnd(N, K, seed=92, scale=K ** -0.5)
+    bias, res = rnd(N, seed=93), rnd(M, N, seed=94)
+    X, Wt = hip.H2.empty(M, Cc), dev_h2(hip, w)
+    hip.split_f32(x.cuda(), X)                                       # the same device split im2col applies
+    col = hip.H2.empty(M, K)
+    hip.im2col3x3(x.cuda(), Bn, H, W, Cc, col)
+    o_ref, o_imp = torch.empty(M, N, device="cuda"), torch.full((M, N), float("nan"), device="cuda")
+    hip.gemm(col, Wt, M, N, K, bias=bias.cuda(), residual=res.cuda(), out_f32=o_ref)
+    hip.gemm(X, Wt, M, N, K, bias=bias.cuda(), residual=res.cuda(), out_f32=o_imp, conv3x3=(H, W, Cc))
+    assert torch.equal(o_ref, o_imp)
+    xi = X.float().cpu().double().reshape(Bn, H, W, Cc).permute(0, 3, 1, 2)
+    wk = Wt.float().cpu().double().reshape(N, 3, 3, Cc).permute(0, 3, 1, 2)
+    ref = F.conv2d(xi, wk, bias.double(), padding=1).permute(0, 2, 3, 1).reshape(M, N) + res.double()
+    assert relerr(o_imp.cpu().double(), ref) < 3e-6
+
+
 def to_head_major(qkv, Bn, S, Hh, hd):
     """[B*S][3][H][hd] -> [3][B][H][S][hd] flattened back to the same (B*S, 3*H*hd) buffer shape."""
     return qkv.reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).contiguous().reshape(Bn * S, 3 * Hh * hd)
