@@ -710,7 +710,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     *(float4*)(eb + fr * EP + sw(fr, nt * 4 + fq)) = make_float4(v[0], v[1], v[2], v[3]);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (g.out_f32) {
+                if (MODE == 0 && g.out_f32) {                        // forms 1 and 2 write h2 planes only (launcher contract)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int row = rowf + 4 * i;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         }
                     }
                 }
-                if (g.out_hi) {
+                if (MODE != 0 || g.out_hi) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int row = rowh + 8 * i;
