@@ -78,6 +78,25 @@ __device__ __forceinline__ float erf_as(float x) {
     return copysignf(r, x);
 }
 
+// The same GELU on two values at once: every step but the reciprocal and the exponential is a packed-f32 instruction
+// (v_pk_mul / v_pk_fma: two values per issue slot), which is what the lin1 epilogue of the ViT blocks spends its time on.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t v) {
+    const f32x2_t x = v * 0.70710678118654752440f;
+    const f32x2_t ax = __builtin_elementwise_abs(x);
+    const f32x2_t d = ax * 0.3275911f + 1.0f;
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2_t p = t * 1.061405429f - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const f32x2_t a = ax * ax * -1.4426950408889634f;                 // exp(-x^2) = exp2(-x^2 log2 e)
+    const f32x2_t e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2_t r = 1.0f - p * t * e;
+    const f32x2_t erf = {copysignf(r.x, x.x), copysignf(r.y, x.y)};
+    return 0.5f * v * (1.0f + erf);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case ACT_GELU: return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f)); // exact-erf GELU

@@ -756,9 +756,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         if (MODE == 1) {
                             const float rstd = ln_rs[mt][i], c = ln_c[mt][i];      // c = mu * rstd
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                v[j] = fmaf(v[j], rstd, fmaf(-c, cs8[j], b8[j]));
-                                if (ACT != ACT_NONE && ACT != ACT_ABS_POST) v[j] = apply_act(v[j], ACT);
+                            for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], rstd, fmaf(-c, cs8[j], b8[j]));
+                            if (ACT == ACT_GELU) {                         // two values per instruction (common.h)
+#pragma unroll
+                                for (int j = 0; j < 8; j += 2) {
+                                    const f32x2_t y = gelu_erf2(f32x2_t{v[j], v[j + 1]});
+                                    v[j] = y.x; v[j + 1] = y.y;
+                                }
+                            } else if (ACT != ACT_NONE && ACT != ACT_ABS_POST) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[j] = apply_act(v[j], ACT);
                             }
                         }
                         if (m < m_lim && nh < g.N) {
