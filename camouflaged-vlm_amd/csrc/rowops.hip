@@ -200,11 +200,16 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 
 // one wave per row: h2 = x * scale, stats = (sum x, sum x^2) of the unscaled row
 __global__ __launch_bounds__(256) void row_stats_split_kernel(const float* __restrict__ x, float scale, half_t* __restrict__ hi,
-                                                              half_t* __restrict__ lo, float* __restrict__ stats, int M, int D) {
+                                                              half_t* __restrict__ lo, float* __restrict__ stats, int M, int D,
+                                                              int64_t dst_row_stride) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (int64_t)row * D;
+    // blockIdx.y: copy number -- the same M source rows land dst_row_stride rows further down for each copy
+    hi += (int64_t)blockIdx.y * dst_row_stride * D;
+    lo += (int64_t)blockIdx.y * dst_row_stride * D;
+    stats += 2 * (int64_t)blockIdx.y * dst_row_stride;
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
         const float4 t = *(const float4*)(xr + c);
@@ -527,10 +532,12 @@ int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, f
     return 0;
 }
 
-int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D, void* stream) {
-    if (!x || !out_hi || !out_lo || !stats || M <= 0 || D <= 0 || (D & 3)) return CVLM_E_BADARG;
-    hipLaunchKernelGGL(row_stats_split_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, scale, (half_t*)out_hi,
-                       (half_t*)out_lo, stats, M, D);
+int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D,
+                         int32_t copies, int64_t dst_row_stride, void* stream) {
+    if (!x || !out_hi || !out_lo || !stats || M <= 0 || D <= 0 || (D & 3) || copies < 1 || copies > 65535) return CVLM_E_BADARG;
+    if (copies > 1 && dst_row_stride < M) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(row_stats_split_kernel, dim3((M + 3) / 4, copies), dim3(256), 0, (hipStream_t)stream, x, scale, (half_t*)out_hi,
+                       (half_t*)out_lo, stats, M, D, dst_row_stride);
     CVLM_CHECK_LAUNCH();
     return 0;
 }

@@ -717,6 +717,17 @@ class ClipModel(_Base):
                         ln2=(self.dev(sd[p + "ln_2.weight"]), self.dev(sd[p + "ln_2.bias"])))
 
         self.vblocks = [block(f"{ie}transformer.resblocks.{i}.", False) for i in range(c.vision_layers)]
+        # vision tower with ln_1 / ln_2 folded into in_proj / c_fc and the residual stream in h2 (as the SAM blocks, §4):
+        # CVLM_CLIP_LN_FOLD=0 keeps the separate LayerNorm passes (the text tower, run once, always does)
+        import os
+        self.ln_fold = os.environ.get("CVLM_CLIP_LN_FOLD", "1") == "1" and c.vision_width % 8 == 0
+        if self.ln_fold:
+            for i, blk in enumerate(self.vblocks):
+                p = f"{ie}transformer.resblocks.{i}."
+                blk["inp_f"] = LnLinear(sd[p + "attn.in_proj.weight"], sd[p + "attn.in_proj.bias"],
+                                        sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], device)
+                blk["fc_f"] = LnLinear(sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"],
+                                       sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], device)
         self.tblocks = [block(f"{te}transformer.resblocks.{i}.", True) for i in range(c.text_layers)]
         self.tpos = self.dev(sd[te + "positional_embedding"])
         self.ln_final = (self.dev(sd[te + "ln_final.weight"]), self.dev(sd[te + "ln_final.bias"]))
@@ -761,6 +772,32 @@ class ClipModel(_Base):
             self.gemm(xn, blk["fc"], M, out_h2=hid, act=ACT_QUICKGELU, out_scale=HID_SCALE)
             self.gemm(hid, blk["pj"], M, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
 
+    def _vision_blocks_folded(self, x: torch.Tensor, Bn: int, L: int, Wd: int, heads: int, first_row: int) -> torch.Tensor:
+        """The vision tower's blocks (alpha_clip_rw/model.py:392-434) on an h2 residual stream: no LayerNorm pass, no f32
+        stream -- `out_proj` / `c_proj` add into the planes and leave the row sums the next folded GEMM normalises with;
+        the deep prompts overwrite planes AND sums (cvlm_row_stats_split, copies = images).  -> class-token rows f32 [Bn][Wd]."""
+        ws, pr, c = self.ws, self.prec, self.c
+        M, inv = Bn * L, 1.0 / X_SCALE
+        xh, qkv, att = ws.h2("vxh", M, Wd), ws.h2("vqkv", M, 3 * Wd), ws.h2("vatt", M, Wd)
+        hid = ws.h2("vhid", M, 4 * Wd)
+        st1, st2 = ws.f32("vst1", M, 2), ws.f32("vst2", M, 2)
+        hip.row_stats_split(x.view(M, Wd), X_SCALE, xh, st1, M, Wd)
+        for i, blk in enumerate(self.vblocks):
+            if 1 <= i <= len(self.deep_vis):
+                hip.row_stats_split(self.deep_vis[i - 1], X_SCALE, xh, st1, c.n_ctx, Wd, row0=first_row, copies=Bn,
+                                    dst_row_stride=L)
+            st2.zero_()
+            self.gemm(xh, blk["inp_f"], M, out_h2=qkv, alpha=inv, ln_fold=(st1, blk["inp_f"].colsum, 1e-5, Wd))
+            self.attention(qkv, att, Bn, L, heads, Wd // heads, mode=0, causal=False, split_qk=pr.qk, split_pv=pr.pv)
+            self.gemm(att, blk["out"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=st2)
+            st1.zero_()
+            self.gemm(xh, blk["fc_f"], M, out_h2=hid, act=ACT_QUICKGELU, out_scale=HID_SCALE, alpha=inv,
+                      ln_fold=(st2, blk["fc_f"].colsum, 1e-5, Wd))
+            self.gemm(hid, blk["pj"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, alpha=1.0 / HID_SCALE,
+                      row_stats=st1)
+        rows = torch.arange(Bn, device=self.device) * L                          # class token = row 0 of every image
+        return (xh.hi[rows].float() + xh.lo[rows].float()) * inv
+
     def image_features(self, image: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
         """alpha_clip_rw/model.py:528-563 -> f32 [B][embed_dim] (un-normalised)."""
         c, ws = self.c, self.ws
@@ -773,9 +810,12 @@ class ClipModel(_Base):
         x = ws.f32("cx", B, L, Wd)
         hip.clip_assemble(pe, self.cls, self.pos, self.shared_ctx, B, P, Wd, c.n_ctx, x)
         hip.layernorm(x, *self.ln_pre, 1e-5, B * L, Wd, out_f32=x)
-        self._blocks(x, self.vblocks, B, L, Wd, c.vision_heads, self.deep_vis, L - c.n_ctx, causal=False)
-        cls = ws.f32("ccls", B, Wd)
-        hip.gather_rows(x, B, L, Wd, None, 0, cls)
+        if self.ln_fold:
+            cls = self._vision_blocks_folded(x, B, L, Wd, c.vision_heads, L - c.n_ctx)
+        else:
+            self._blocks(x, self.vblocks, B, L, Wd, c.vision_heads, self.deep_vis, L - c.n_ctx, causal=False)
+            cls = ws.f32("ccls", B, Wd)
+            hip.gather_rows(x, B, L, Wd, None, 0, cls)
         ch = ws.h2("cclsh", B, Wd)
         hip.layernorm(cls, *self.ln_post, 1e-5, B, Wd, out_h2=ch)
         out = ws.f32("cfeat", B, c.embed_dim)

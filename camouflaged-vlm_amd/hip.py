@@ -230,9 +230,12 @@ def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], b_rows: int, M: int, D:
         C.c_int32(M), C.c_int32(D), C.c_void_p(_stream())), "cvlm_add_rows")
 
 
-def row_stats_split(x: torch.Tensor, scale: float, out: H2, stats: torch.Tensor, M: int, D: int) -> None:
-    _check(load().cvlm_row_stats_split(C.c_void_p(x.data_ptr()), C.c_float(scale), C.c_void_p(out.hi.data_ptr()),
-                                       C.c_void_p(out.lo.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_int32(M), C.c_int32(D),
+def row_stats_split(x: torch.Tensor, scale: float, out: H2, stats: torch.Tensor, M: int, D: int, *, row0: int = 0,
+                    copies: int = 1, dst_row_stride: int = 0) -> None:
+    """out rows [row0 + c * dst_row_stride + m] = x[m] * scale as h2, stats likewise (sum, sum of squares of the unscaled row)."""
+    _check(load().cvlm_row_stats_split(C.c_void_p(x.data_ptr()), C.c_float(scale), C.c_void_p(out.hi.data_ptr() + 2 * row0 * D),
+                                       C.c_void_p(out.lo.data_ptr() + 2 * row0 * D), C.c_void_p(stats.data_ptr() + 8 * row0),
+                                       C.c_int32(M), C.c_int32(D), C.c_int32(copies), C.c_int64(dst_row_stride),
                                        C.c_void_p(_stream())), "cvlm_row_stats_split")
 
 

@@ -110,8 +110,12 @@ int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, f
                   void* out_hi, void* out_lo, int32_t M, int32_t D, void* stream);
 
 /* Row statistics + split: out h2 = x * scale (both planes), stats[m] = (sum_d x, sum_d x^2) of the unscaled row (overwritten).
- * Seeds the h2 residual stream of the LayerNorm-folded GEMMs (cvlm_gemm_args.ln_stats) from an f32 tensor x [M][D]. */
-int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D, void* stream);
+ * Seeds the h2 residual stream of the LayerNorm-folded GEMMs (cvlm_gemm_args.ln_stats) from an f32 tensor x [M][D].
+ * copies > 1 (ABI 4): the same M rows are written `copies` times, copy c at rows c * dst_row_stride of out / stats -- the
+ * MaPLe deep visual prompts that replace the last n_ctx tokens of every image before a block
+ * (alpha_clip_rw/model.py:392-434) on an h2 stream: out = planes + first_row * D, stats + 2 * first_row, stride = L. */
+int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D,
+                         int32_t copies, int64_t dst_row_stride, void* stream);
 
 /* f32 -> h2 planes (elementwise split), n elements.  No reference counterpart: it produces the operand format of
  * cvlm_gemm / cvlm_attention from tensors the reference keeps in fp32 (e.g. the sparse prompts, models/sam_maskdecoder_edge.py:342-344). */

@@ -248,6 +248,22 @@ def test_gemm_implicit_conv3x3(hip, Bn, H, W, Cc, N):
     assert relerr(o_imp.cpu().double(), ref) < 3e-6
 
 
+def test_row_stats_split_copies(hip):
+    """cvlm_row_stats_split with copies: the MaPLe deep prompts overwrite the last n rows of every image on an h2 stream."""
+    Bn, L, D, n, first, XS = 3, 21, 64, 4, 17, 0.25
+    base = rnd(Bn * L, D, seed=61)
+    src = rnd(n, D, seed=62) * 3.0
+    xh, st = hip.H2.empty(Bn * L, D), torch.empty(Bn * L, 2, device="cuda")
+    hip.row_stats_split(base.cuda(), XS, xh, st, Bn * L, D)
+    hip.row_stats_split(src.cuda(), XS, xh, st, n, D, row0=first, copies=Bn, dst_row_stride=L)
+    want = base.clone().reshape(Bn, L, D)
+    want[:, first:first + n] = src
+    want = want.reshape(Bn * L, D)
+    assert relerr(xh.float().cpu().double() / XS, want.double()) < 3e-7
+    s_ref = torch.stack([want.double().sum(1), (want.double() ** 2).sum(1)], 1)
+    assert float(((st.cpu().double() - s_ref).abs() / (s_ref.abs() + 1.0)).max()) < 2e-6
+
+
 def to_head_major(qkv, Bn, S, Hh, hd):
     """[B*S][3][H][hd] -> [3][B][H][S][hd] flattened back to the same (B*S, 3*H*hd) buffer shape."""
     return qkv.reshape(Bn, S, 3, Hh, hd).permute(2, 0, 3, 1, 4).contiguous().reshape(Bn * S, 3 * Hh * hd)
