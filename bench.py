@@ -101,8 +101,8 @@ class PowerSampler:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "exact"), choices=["exact", "mixed", "fast"])
     ap.add_argument("--geometry", default="demo", choices=["demo", "tiny", "hires1536"])
