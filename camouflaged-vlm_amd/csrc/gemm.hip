@@ -648,36 +648,77 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             float ln_rs[MT][2], ln_c[MT][2];                          // MODE 1: rstd and mu * rstd of this lane's 2 * MT rows
             if (MODE == 1) {
                 const float ln_inv_d = 1.0f / (float)g.ln_D;
+                // Row statistics arrive as per-piece pairs (include/cvlm.h: ln_stats[p][m] = (sum, centred sum of squares) of
+                // columns [64p, 64p + 64) of row m, written with plain stores by the producer -- no atomics, no memset, fixed
+                // summation order).  The workgroup merges them once per tile: TPR threads per tile row add the even / odd pieces
+                // (the order does not depend on TPR), combine, and leave (rstd, mu * rstd) in LDS, from where every lane takes
+                // its 2 * MT rows.  v_rsq instead of an IEEE sqrt + divide (7 us per 256^2 tile in the first version).
+                constexpr int TPR = NWAVE * 64 / BM;
+                static_assert(TPR == 1 || TPR == 2, "row-statistics merge: one or two threads per tile row");
+                float2* sbuf = (float2*)(smem + (PERSIST ? 2 * STAGE : 0));
+                {
+                    const int r = tid / TPR, h = tid - r * TPR;
+                    int m = e_bm + r;
+                    m = m < g.M ? m : g.M - 1;
+                    const int P = (g.ln_D + 63) >> 6;
+                    const float2* sp = (const float2*)g.ln_stats + m;
+                    float tot = 0.f;
+                    if (TPR == 2) {
+                        float a = 0.f;
+                        for (int pc = h; pc < P; pc += 2) a += sp[(int64_t)pc * g.M].x;
+                        tot = a + __shfl_xor(a, 1, 64);
+                    } else {
+                        float a0 = 0.f, a1 = 0.f;
+                        for (int pc = 0; pc < P; pc += 2) a0 += sp[(int64_t)pc * g.M].x;
+                        for (int pc = 1; pc < P; pc += 2) a1 += sp[(int64_t)pc * g.M].x;
+                        tot = a0 + a1;
+                    }
+                    const float mu = tot * ln_inv_d;
+                    // M2 = sum_p m2_p + n_p * (s1_p / n_p - mu)^2   (pairwise merge of centred moments: no s2 / D - mu^2
+                    // cancellation for rows whose mean dwarfs their spread)
+                    auto part = [&](int pc) -> float {
+                        const float2 v = sp[(int64_t)pc * g.M];
+                        const int np = g.ln_D - (pc << 6) < 64 ? g.ln_D - (pc << 6) : 64;
+                        const float dm = v.x * (np == 64 ? 0.015625f : 1.0f / (float)np) - mu;
+                        return fmaf((float)np * dm, dm, v.y);
+                    };
+                    float m2 = 0.f;
+                    if (TPR == 2) {
+                        float a = 0.f;
+                        for (int pc = h; pc < P; pc += 2) a += part(pc);
+                        m2 = a + __shfl_xor(a, 1, 64);
+                    } else {
+                        float a0 = 0.f, a1 = 0.f;
+                        for (int pc = 0; pc < P; pc += 2) a0 += part(pc);
+                        for (int pc = 1; pc < P; pc += 2) a1 += part(pc);
+                        m2 = a0 + a1;
+                    }
+                    const float rs = __builtin_amdgcn_rsqf(fmaxf(m2 * ln_inv_d, 0.f) + g.ln_eps);
+                    if (h == 0) sbuf[r] = make_float2(rs, mu * rs);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float2 v = sbuf[wm * WROWS + mt * 16 + rowh + 8 * i];
+                        ln_rs[mt][i] = v.x;
+                        ln_c[mt][i] = v.y;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                            // sbuf aliases wave 0's staging slab
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool okc = nh + j < g.N;
                     cs8[j] = okc ? g.ln_colsum[nh + j] : 0.f;
                     b8[j] = (okc && g.bias) ? g.bias[nh + j] : 0.f;
                 }
-                // all row statistics of the tile up front (one batch of loads, v_rsq instead of an IEEE sqrt + divide per
-                // row piece: the first version spent ~7 us per 256^2 tile here, as much as the LayerNorm pass it replaces)
-                float2 st[MT][2];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        int m = mw + mt * 16 + rowh + 8 * i;
-                        m = m < g.M ? m : g.M - 1;
-                        st[mt][i] = *(const float2*)(g.ln_stats + 2 * (int64_t)m);
-                    }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float mu = st[mt][i].x * ln_inv_d;
-                        const float rs = __builtin_amdgcn_rsqf(fmaxf(st[mt][i].y * ln_inv_d - mu * mu, 0.f) + g.ln_eps);
-                        ln_rs[mt][i] = rs;
-                        ln_c[mt][i] = mu * rs;
-                    }
             }
             // MODE 2: the residual planes of slab mt + 1 are requested before slab mt is staged -- asked for where they are
             // used, each of the 16 row pieces of a wave waited out a full HBM/L2 latency (proj 286 -> 358 us)
-            float ps1[8], ps2[8];                                     // MODE 2: row sums of the last four slabs (8 row pieces per lane group)
+            float ps1[8], ps2[8];                                     // MODE 2: piece statistics of the last four slabs (8 row pieces per lane group)
+            [[maybe_unused]] const float piece_inv_n = g.N - n0 >= 64 ? 0.015625f : 1.0f / (float)(g.N - n0 > 0 ? g.N - n0 : 1);
             half8 res_h[2][2], res_l[2][2];
             auto load_res = [&](int mt_, int buf) {
 #pragma unroll
@@ -736,20 +777,27 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         const float4 t1 = *(const float4*)(eb + row * EP + sw(row, (lane & 7) * 2 + 1));
                         float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
                         if (MODE == 2) {
-                            float s1 = 0.f, s2 = 0.f;
-                            if (m < m_lim && nh < g.N) {
-                                if (have_res) {
-                                    const half8 rh = res_h[mt & 1][i], rl = res_l[mt & 1][i];
+                            const bool live = m < m_lim && nh < g.N;
+                            if (live && have_res) {
+                                const half8 rh = res_h[mt & 1][i], rl = res_l[mt & 1][i];
 #pragma unroll
-                                    for (int j = 0; j < 8; ++j) v[j] += ((float)rh[j] + (float)rl[j]) * g.res_scale;
-                                }
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 += v[j] * v[j]; }
+                                for (int j = 0; j < 8; ++j) v[j] += ((float)rh[j] + (float)rl[j]) * g.res_scale;
                             }
-                            if (g.row_stats) {                             // the 8 lanes of a row: three exchange steps, every lane ends with the sums
-                                s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-                                s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
-                                s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+                            if (g.row_stats) {
+                                // the 8 lanes of a row piece: three exchange steps for the sum, the piece mean, three more for
+                                // the centred squares; every lane ends with both
+                                float s1 = 0.f, s2 = 0.f;
+                                if (live) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) s1 += v[j];
+                                }
+                                s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+                                const float pm = s1 * piece_inv_n;
+                                if (live) {
+#pragma unroll
+                                    for (int j = 0; j < 8; ++j) { const float d = v[j] - pm; s2 = fmaf(d, d, s2); }
+                                }
+                                s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
                                 ps1[(mt & 3) * 2 + i] = s1; ps2[(mt & 3) * 2 + i] = s2;
                             }
                         }
@@ -803,20 +851,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         }
                     }
                 }
-                if (MODE == 2 && (mt & 3) == 3 && g.row_stats) {
-                    // Float atomics execute at the memory side, one wave-instruction per ~50 ns per CU whatever the number of
-                    // active lanes (MI355X_MICROARCH.md): one pair per row piece (8 active lanes, 32 instructions per wave
-                    // and tile) cost 12.8 us of a ~110-us tile.  Here the 64 row pieces of four slabs go out as ONE pair
-                    // with all lanes active: lane (r, q) adds row piece q of row group r.
+                if (MODE == 2 && (mt & 3) == 3 && g.row_stats && n0 < g.N) {
+                    // The 64 row pieces of four slabs go out as ONE 512-byte store with all lanes active: lane (r, q) writes row
+                    // piece q of row group r into this wave's piece plane, row_stats[piece][m] (plain stores: the consumer adds
+                    // the pieces of a row in a fixed order, so the statistics are bit-reproducible and need no zeroing).
                     const int q = lane & 7;
                     float a1 = ps1[0], a2 = ps2[0];
 #pragma unroll
                     for (int k = 1; k < 8; ++k) { a1 = (q == k) ? ps1[k] : a1; a2 = (q == k) ? ps2[k] : a2; }
                     const int m = mw + (mt - 3 + (q >> 1)) * 16 + rowh + 8 * (q & 1);
-                    if (m < m_lim) {
-                        atomicAdd(g.row_stats + 2 * (int64_t)m, a1);
-                        atomicAdd(g.row_stats + 2 * (int64_t)m + 1, a2);
-                    }
+                    if (m < m_lim) *(float2*)(g.row_stats + 2 * ((int64_t)(n0 >> 6) * g.M + m)) = make_float2(a1, a2);
                 }
                 if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab fully read before it is overwritten
                 // PERSIST: the next tile's K-tiles 0 / 1 (requested before this epilogue) have had two slabs' time to land; the

@@ -198,10 +198,12 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     }
 }
 
-// one wave per row: h2 = x * scale, stats = (sum x, sum x^2) of the unscaled row
+// one wave per row: h2 = x * scale; stats[p][row] = (sum, centred sum of squares) of columns [64p, 64p + 64) of the unscaled
+// row -- the piece layout the LayerNorm-folded GEMM merges (include/cvlm.h).  A lane takes 8 consecutive columns, the 8 lanes
+// of a piece exchange their partial sums.
 __global__ __launch_bounds__(256) void row_stats_split_kernel(const float* __restrict__ x, float scale, half_t* __restrict__ hi,
                                                               half_t* __restrict__ lo, float* __restrict__ stats, int M, int D,
-                                                              int64_t dst_row_stride) {
+                                                              int64_t dst_row_stride, int64_t stats_rows) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -210,17 +212,33 @@ __global__ __launch_bounds__(256) void row_stats_split_kernel(const float* __res
     hi += (int64_t)blockIdx.y * dst_row_stride * D;
     lo += (int64_t)blockIdx.y * dst_row_stride * D;
     stats += 2 * (int64_t)blockIdx.y * dst_row_stride;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        const float4 t = *(const float4*)(xr + c);
-        s1 += (t.x + t.y) + (t.z + t.w);
-        s2 += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
-        const float o[4] = {t.x * scale, t.y * scale, t.z * scale, t.w * scale};
-        store_h2x4(hi, lo, (int64_t)row * D + c, o);
+    const int nchunk = D >> 3;
+    for (int c0 = 0; c0 < nchunk; c0 += 64) {                         // wave-uniform trip count: the exchanges need every lane
+        const int ch = c0 + lane;
+        const bool live = ch < nchunk;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const float4 t0 = *(const float4*)(xr + ch * 8), t1 = *(const float4*)(xr + ch * 8 + 4);
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+            const float o0[4] = {t0.x * scale, t0.y * scale, t0.z * scale, t0.w * scale};
+            const float o1[4] = {t1.x * scale, t1.y * scale, t1.z * scale, t1.w * scale};
+            store_h2x4(hi, lo, (int64_t)row * D + ch * 8, o0);
+            store_h2x4(hi, lo, (int64_t)row * D + ch * 8 + 4, o1);
+        }
+        const int piece = ch >> 3;
+        const int np = D - piece * 64 < 64 ? D - piece * 64 : 64;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += v[j];
+        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+        const float pm = s1 * (np == 64 ? 0.015625f : 1.0f / (float)(np > 0 ? np : 1));
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - pm; s2 = fmaf(d, d, s2); }
+        }
+        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+        if (live && (lane & 7) == 0) *(float2*)(stats + 2 * ((int64_t)piece * stats_rows + row)) = make_float2(s1, s2);
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if (lane == 0) { stats[2 * (int64_t)row] = s1; stats[2 * (int64_t)row + 1] = s2; }
 }
 
 __global__ __launch_bounds__(256) void dense_pe_kernel(const float* __restrict__ gauss, int size, int C,
@@ -337,6 +355,21 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
         const int64_t b = i / wv;
         const int r = idx ? idx[b] : fixed;
         ((float4*)out)[i] = ((const float4*)x)[(b * L + r) * wv + c];
+    }
+}
+
+// the same pick from an h2 stream: out[b] = (hi + lo)[b][r] * scale
+__global__ __launch_bounds__(256) void gather_rows_h2_kernel(const half_t* __restrict__ hi, const half_t* __restrict__ lo, float scale,
+                                                             int L, int Wd, const int32_t* __restrict__ idx, int fixed,
+                                                             float* __restrict__ out, int64_t total) {
+    const int wv = Wd >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % wv);
+        const int64_t b = i / wv;
+        const int r = idx ? idx[b] : fixed;
+        const half4 h = ((const half4*)hi)[(b * L + r) * wv + c], l = ((const half4*)lo)[(b * L + r) * wv + c];
+        ((float4*)out)[i] = make_float4(((float)h[0] + (float)l[0]) * scale, ((float)h[1] + (float)l[1]) * scale,
+                                        ((float)h[2] + (float)l[2]) * scale, ((float)h[3] + (float)l[3]) * scale);
     }
 }
 
@@ -532,12 +565,13 @@ int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, f
     return 0;
 }
 
-int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D,
-                         int32_t copies, int64_t dst_row_stride, void* stream) {
-    if (!x || !out_hi || !out_lo || !stats || M <= 0 || D <= 0 || (D & 3) || copies < 1 || copies > 65535) return CVLM_E_BADARG;
+int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int64_t stats_rows, int32_t M,
+                         int32_t D, int32_t copies, int64_t dst_row_stride, void* stream) {
+    if (!x || !out_hi || !out_lo || !stats || M <= 0 || D <= 0 || (D & 7) || copies < 1 || copies > 65535) return CVLM_E_BADARG;
     if (copies > 1 && dst_row_stride < M) return CVLM_E_BADARG;
+    if (stats_rows < M + (int64_t)(copies - 1) * dst_row_stride) return CVLM_E_BADARG;
     hipLaunchKernelGGL(row_stats_split_kernel, dim3((M + 3) / 4, copies), dim3(256), 0, (hipStream_t)stream, x, scale, (half_t*)out_hi,
-                       (half_t*)out_lo, stats, M, D, dst_row_stride);
+                       (half_t*)out_lo, stats, M, D, dst_row_stride, stats_rows);
     CVLM_CHECK_LAUNCH();
     return 0;
 }
@@ -633,6 +667,16 @@ int cvlm_gather_rows(const float* x, int32_t B, int32_t L, int32_t W, const int3
     const int64_t total = (int64_t)B * (W >> 2);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, L, W, idx,
                        fixed, out, total);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_gather_rows_h2(const void* x_hi, const void* x_lo, float scale, int32_t B, int32_t L, int32_t W, const int32_t* idx,
+                        int32_t fixed, float* out, void* stream) {
+    if (!x_hi || !x_lo || !out || (W & 3) || B <= 0 || L <= 0) return CVLM_E_BADARG;
+    const int64_t total = (int64_t)B * (W >> 2);
+    hipLaunchKernelGGL(gather_rows_h2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x_hi,
+                       (const half_t*)x_lo, scale, L, W, idx, fixed, out, total);
     CVLM_CHECK_LAUNCH();
     return 0;
 }

@@ -23,9 +23,9 @@ EXPORTS = [
     "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
-    "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split",
+    "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GemmArgs(C.Structure):
@@ -176,8 +176,9 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          row_stats: Optional[torch.Tensor] = None, conv3x3: Optional[Tuple[int, int, int]] = None) -> None:
     """conv3x3 = (H, W, C): `a` is an NHWC image [B*H*W][C] and K = 9*C runs over the taps of a 3x3 / pad 1 convolution
     (implicit GEMM: the im2col gather happens in the DMA addresses).
-    ln_fold = (stats [M][2] f32, colsum [N] f32, eps, D): LayerNorm of the input folded into this GEMM (include/cvlm.h);
-    residual_h2 = (x h2, scale): residual given as h2 planes; row_stats [M][2] f32: += (sum, sum of squares) of the result rows."""
+    ln_fold = (stats [ceil(D/64)][M][2] f32, colsum [N] f32, eps, D): LayerNorm of the input folded into this GEMM (include/cvlm.h);
+    residual_h2 = (x h2, scale): residual given as h2 planes; row_stats [ceil(N/64)][M][2] f32: piece statistics of the result rows
+    (plain stores, bit-reproducible: nothing to zero)."""
     _on_current_device(a.t)
     g = GemmArgs()
     g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
@@ -196,11 +197,13 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
         g.hm_S, g.hm_H, g.hm_hd = head_major
     g.out_scale = out_scale
     if ln_fold is not None:
+        assert tuple(ln_fold[0].shape) == (stats_pieces(ln_fold[3]), M, 2) and ln_fold[0].is_contiguous(), "ln_fold stats: [pieces][M][2]"
         g.ln_stats, g.ln_colsum, g.ln_eps, g.ln_D = ln_fold[0].data_ptr(), ln_fold[1].data_ptr(), ln_fold[2], ln_fold[3]
     if residual_h2 is not None:
         r, rs = residual_h2
         g.res_hi, g.res_lo, g.ldrh, g.res_scale = r.hi.data_ptr(), r.lo.data_ptr(), (ldrh if ldrh is not None else N), rs
     if row_stats is not None:
+        assert tuple(row_stats.shape) == (stats_pieces(N), M, 2) and row_stats.is_contiguous(), "row_stats: [pieces][M][2]"
         g.row_stats = row_stats.data_ptr()
     if conv3x3 is not None:
         g.conv_h, g.conv_w, g.conv_c = conv3x3
@@ -230,13 +233,20 @@ def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], b_rows: int, M: int, D:
         C.c_int32(M), C.c_int32(D), C.c_void_p(_stream())), "cvlm_add_rows")
 
 
+def stats_pieces(D: int) -> int:
+    """Piece planes of a row-statistics buffer for rows of D columns (include/cvlm.h: one (sum, centred squares) pair per 64 columns)."""
+    return (D + 63) // 64
+
+
 def row_stats_split(x: torch.Tensor, scale: float, out: H2, stats: torch.Tensor, M: int, D: int, *, row0: int = 0,
                     copies: int = 1, dst_row_stride: int = 0) -> None:
-    """out rows [row0 + c * dst_row_stride + m] = x[m] * scale as h2, stats likewise (sum, sum of squares of the unscaled row)."""
+    """out rows [row0 + c * dst_row_stride + m] = x[m] * scale as h2; stats f32 [pieces][rows][2] gets the piece statistics of the
+    same rows (sum, centred sum of squares per 64 columns of the unscaled row)."""
+    assert stats.dim() == 3 and stats.shape[0] == stats_pieces(D) and stats.shape[2] == 2 and stats.is_contiguous()
     _check(load().cvlm_row_stats_split(C.c_void_p(x.data_ptr()), C.c_float(scale), C.c_void_p(out.hi.data_ptr() + 2 * row0 * D),
                                        C.c_void_p(out.lo.data_ptr() + 2 * row0 * D), C.c_void_p(stats.data_ptr() + 8 * row0),
-                                       C.c_int32(M), C.c_int32(D), C.c_int32(copies), C.c_int64(dst_row_stride),
-                                       C.c_void_p(_stream())), "cvlm_row_stats_split")
+                                       C.c_int64(stats.shape[1]), C.c_int32(M), C.c_int32(D), C.c_int32(copies),
+                                       C.c_int64(dst_row_stride), C.c_void_p(_stream())), "cvlm_row_stats_split")
 
 
 def split_f32(x: torch.Tensor, out: H2) -> None:
@@ -338,6 +348,13 @@ def overwrite_rows(x, B: int, L: int, W: int, first: int, n: int, src) -> None:
     _check(load().cvlm_overwrite_rows(C.c_void_p(x.data_ptr()), C.c_int32(B), C.c_int32(L), C.c_int32(W),
                                       C.c_int32(first), C.c_int32(n), C.c_void_p(src.data_ptr()),
                                       C.c_void_p(_stream())), "cvlm_overwrite_rows")
+
+
+def gather_rows_h2(x: H2, scale: float, B: int, L: int, W: int, idx, fixed: int, out) -> None:
+    """out[b] = (hi + lo)[b][idx[b] or fixed] * scale: one row per sequence of an h2 stream [B][L][W] as f32."""
+    _check(load().cvlm_gather_rows_h2(C.c_void_p(x.hi.data_ptr()), C.c_void_p(x.lo.data_ptr()), C.c_float(scale), C.c_int32(B),
+                                      C.c_int32(L), C.c_int32(W), C.c_void_p(_p(idx)), C.c_int32(fixed),
+                                      C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), "cvlm_gather_rows_h2")
 
 
 def gather_rows(x, B: int, L: int, W: int, idx, fixed: int, out) -> None:

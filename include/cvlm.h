@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 4
+#define CVLM_ABI_VERSION 5
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -74,13 +74,18 @@ typedef struct cvlm_gemm_args {
     int64_t workspace_bytes;     /* ABI 2 */
     /* ABI 3 -- LayerNorm folded into the GEMM that consumes it (image_encoder.py:432,444 + :491 / common.py:25): with
      * W' = W.diag(gamma) packed as the weight, bias' = bias + W.beta and ln_colsum[n] = sum_k W'[n][k],
-     *     out = act( rstd_m * (alpha * acc - mu_m * ln_colsum[n]) + bias'[n] ),   mu = s1 / ln_D,  rstd = 1 / sqrt(s2 / ln_D - mu^2 + ln_eps)
-     * where (s1, s2) = ln_stats[m] are the sums of x and x^2 over row m of the UN-normalised input (A holds x, possibly
-     * scaled: alpha carries the inverse).  h2 output only, act in {NONE, GELU, QUICKGELU}, N % 8 == 0. */
+     *     out = act( rstd_m * (alpha * acc - mu_m * ln_colsum[n]) + bias'[n] ),   mu = mean of row m,  rstd = 1 / sqrt(var + ln_eps)
+     * of the UN-normalised input (A holds x, possibly scaled: alpha carries the inverse).  ABI 5: the statistics arrive in
+     * PIECES, ln_stats[p][m] = (sum, centred sum of squares) of columns [64p, 64p + 64) of row m, p < ceil(ln_D / 64), piece
+     * planes M rows apart (float [P][M][2]; the layout `row_stats` of the producing launch and cvlm_row_stats_split write).
+     * The consumer merges the pieces of a row in a fixed order (even pieces, odd pieces, then the two), so the result is
+     * bit-reproducible, and as centred moments (no s2 / D - mu^2 cancellation on rows whose mean dwarfs their spread).
+     * h2 output only, act in {NONE, GELU, QUICKGELU}, N % 8 == 0. */
     const float* ln_stats; const float* ln_colsum; float ln_eps; int32_t ln_D;
     /* ABI 3 -- the producer side: residual given as h2 planes (value = (hi + lo) * res_scale, leading dimension ldrh) and
-     * row_stats[m] += (sum_n v, sum_n v^2) of the final values v of this launch's columns (atomic adds: zero it first).
-     * h2 output only, act NONE, N % 8 == 0.  Together the two forms keep a pre-norm residual stream in h2 between the
+     * row_stats[p][m] = (sum, centred sum of squares) of the final values v of columns [64p, 64p + 64) of row m (ABI 5:
+     * float [ceil(N / 64)][M][2], plain stores -- nothing to zero, no atomics; ABI 3/4 accumulated (sum, sum of squares) with
+     * atomic adds).  h2 output only, act NONE, N % 8 == 0.  Together the two forms keep a pre-norm residual stream in h2 between the
      * GEMMs of a transformer block with no separate LayerNorm pass. */
     const void* res_hi; const void* res_lo; int64_t ldrh; float res_scale;
     float* row_stats;
@@ -109,13 +114,14 @@ int cvlm_layernorm(const float* x, int64_t ldx, const float* add, int32_t add_ro
 int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, float* out_f32,
                   void* out_hi, void* out_lo, int32_t M, int32_t D, void* stream);
 
-/* Row statistics + split: out h2 = x * scale (both planes), stats[m] = (sum_d x, sum_d x^2) of the unscaled row (overwritten).
+/* Row statistics + split: out h2 = x * scale (both planes), stats[p][m] = (sum, centred sum of squares) of columns
+ * [64p, 64p + 64) of the unscaled row m, piece planes `stats_rows` rows apart (the piece layout of cvlm_gemm_args.ln_stats; D % 8 == 0).
  * Seeds the h2 residual stream of the LayerNorm-folded GEMMs (cvlm_gemm_args.ln_stats) from an f32 tensor x [M][D].
  * copies > 1 (ABI 4): the same M rows are written `copies` times, copy c at rows c * dst_row_stride of out / stats -- the
  * MaPLe deep visual prompts that replace the last n_ctx tokens of every image before a block
  * (alpha_clip_rw/model.py:392-434) on an h2 stream: out = planes + first_row * D, stats + 2 * first_row, stride = L. */
-int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int32_t M, int32_t D,
-                         int32_t copies, int64_t dst_row_stride, void* stream);
+int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int64_t stats_rows, int32_t M,
+                         int32_t D, int32_t copies, int64_t dst_row_stride, void* stream);
 
 /* f32 -> h2 planes (elementwise split), n elements.  No reference counterpart: it produces the operand format of
  * cvlm_gemm / cvlm_attention from tensors the reference keeps in fp32 (e.g. the sparse prompts, models/sam_maskdecoder_edge.py:342-344). */
@@ -210,6 +216,10 @@ int cvlm_overwrite_rows(float* x, int32_t B, int32_t L, int32_t W, int32_t first
  * `x[arange, tokenized_prompts.argmax(-1)]` (cocotrainers/mapleAlphaCLIP.py:76). */
 int cvlm_gather_rows(const float* x, int32_t B, int32_t L, int32_t W, const int32_t* idx, int32_t fixed,
                      float* out, void* stream);
+/* ABI 5: the same pick from a residual stream kept in h2 planes: out[b] = (hi + lo)[b][idx[b]] * scale (f32).  The class-token
+ * rows at the end of the LayerNorm-folded CLIP vision tower (alpha_clip_rw/model.py:556). */
+int cvlm_gather_rows_h2(const void* x_hi, const void* x_lo, float scale, int32_t B, int32_t L, int32_t W, const int32_t* idx,
+                        int32_t fixed, float* out, void* stream);
 
 /* CLIP head (cocotrainers/mapleAlphaCLIP.py:289-294): img f32 [B][D] (un-normalised), txt f32 [C][D]
  * (= normalise(text features) + bank, precomputed), logit_scale_exp.  Outputs: img_n [B][D],

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/cvlm.h but not exported"
     assert set(hip.EXPORTS) == declared
-    assert lib.cvlm_abi_version() == hip.ABI_VERSION == 4 and lib.cvlm_target_arch() == b"gfx950"
+    assert lib.cvlm_abi_version() == hip.ABI_VERSION == 5 and lib.cvlm_target_arch() == b"gfx950"
 
 
 def test_integration_doc_struct_matches_binding():
@@ -377,3 +377,109 @@ def test_dassl_checkpoint_drops_the_fixed_token_vectors(tmp_path):
     assert float(after["prompt_learner.ctx"].mean()) == 0.25 and float(after["prompt_learner.token_prefix_test"].mean()) == 3.0
     assert torch.equal(after["image_encoder.proj"], before["image_encoder.proj"])
     assert clip._engine is None and clip._engine_text_dirty
+
+
+# ---- launcher: the reference's own scripts resolve `models` / `cocotrainers` / `recorder` to the drop-in ----------------
+_DECOY = 'raise ImportError("the CHECKOUT\'s own %s package was imported (reference classes: mmcv / open_clip needed)")\n'
+_DEMO_SHAPED = '''
+import argparse
+import os
+os.environ["CUDA_VISIBLE_DEVICES"] = '3'                      # demo.py:3
+import json
+import sys
+import models                                                 # demo.py:7
+import recorder                                               # test_ovcos_maskdecoder_edge.py:12
+from cocotrainers.mapleAlphaCLIP import TestMaPLeAlphaCLIP    # demo.py:11
+from recorder.new_evaluator import Classification             # test_ovcos_maskdecoder_edge.py:18
+from datasets.ovcamo_info.class_names import TRAIN_CLASS_NAMES, TEST_CLASS_NAMES   # demo.py:13: the checkout's package
+import utils                                                  # test_ovcos_maskdecoder_edge.py:9: the checkout's module
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--config', default="./configs/demo.yaml")
+    args = parser.parse_args()
+    print("RESULT " + json.dumps({
+        "models": models.__file__, "cocotrainers": sys.modules["cocotrainers"].__file__, "recorder": recorder.__file__,
+        "datasets": sys.modules["datasets"].__file__, "utils": utils.__file__, "registry": sorted(models.models.models),
+        "make": callable(models.make), "register": callable(models.register), "config": args.config,
+        "argv0": sys.argv[0], "n_test": len(TEST_CLASS_NAMES), "name": __name__,
+        "TestMaPLeAlphaCLIP": TestMaPLeAlphaCLIP.__module__, "Classification": Classification.__module__}))
+'''
+
+
+def _fake_checkout(root):
+    """A directory shaped like the reference checkout: its own `models`, `cocotrainers`, `recorder` packages (decoys that
+    raise, standing for classes that need mmcv / open_clip), a `datasets` package and a `utils` module that must keep
+    resolving to the checkout (pip's HuggingFace `datasets` is installed in this image), and a demo.py-shaped script."""
+    for pkg in ("models", "cocotrainers", "recorder"):
+        os.makedirs(os.path.join(root, pkg))
+        with open(os.path.join(root, pkg, "__init__.py"), "w") as f:
+            f.write(_DECOY % pkg)
+    with open(os.path.join(root, "cocotrainers", "mapleAlphaCLIP.py"), "w") as f:
+        f.write(_DECOY % "cocotrainers.mapleAlphaCLIP")
+    os.makedirs(os.path.join(root, "datasets", "ovcamo_info"))
+    for p in ("datasets/__init__.py", "datasets/ovcamo_info/__init__.py"):
+        open(os.path.join(root, p), "w").close()
+    with open(os.path.join(root, "datasets", "ovcamo_info", "class_names.py"), "w") as f:
+        f.write("TRAIN_CLASS_NAMES = ['a', 'b']\nTEST_CLASS_NAMES = ['c', 'd', 'e']\n")
+    with open(os.path.join(root, "utils.py"), "w") as f:
+        f.write("def log(*a, **k):\n    pass\n")
+    with open(os.path.join(root, "demo.py"), "w") as f:
+        f.write(_DEMO_SHAPED)
+    return os.path.join(root, "demo.py")
+
+
+def _run_in_checkout(checkout, cmd, pythonpath):
+    env = dict(os.environ, PYTHONPATH=pythonpath)
+    return subprocess.run(cmd, cwd=checkout, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_launcher_resolves_dropin_packages_from_the_reference_checkout(tmp_path):
+    """INTEGRATION.md section 1, as documented: from the checkout, `PYTHONPATH=<repo> python -m camouflaged_vlm_amd.run
+    demo.py ...` -- `models`, `cocotrainers`, `recorder` come from the drop-in although the checkout has packages of the
+    same names next to the script; `datasets` / `utils` still come from the checkout; the script sees its own argv."""
+    import json
+    checkout = str(tmp_path / "checkout")
+    os.makedirs(checkout)
+    _fake_checkout(checkout)
+    # the failure mode the launcher exists for: plain `python demo.py` with PYTHONPATH picks the checkout's package
+    r = _run_in_checkout(checkout, [sys.executable, "demo.py"], os.pathsep.join([cv.DROPIN_DIR, REPO]))
+    assert r.returncode != 0 and "CHECKOUT's own models package" in r.stderr
+    r = _run_in_checkout(checkout, [sys.executable, "-m", "camouflaged_vlm_amd.run", "demo.py", "--config", "x.yaml"], REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    drop = os.path.realpath(cv.DROPIN_DIR) + os.sep
+    for pkg in ("models", "cocotrainers", "recorder"):
+        assert os.path.realpath(res[pkg]).startswith(drop), (pkg, res[pkg])
+    for mod in ("datasets", "utils"):
+        assert os.path.realpath(res[mod]).startswith(os.path.realpath(checkout) + os.sep), (mod, res[mod])
+    assert res["registry"] == ["sam", "sam_maskdecoder_edge"] and res["make"] and res["register"]
+    assert res["config"] == "x.yaml" and res["argv0"] == "demo.py" and res["n_test"] == 3 and res["name"] == "__main__"
+    assert res["TestMaPLeAlphaCLIP"] == "cocotrainers.mapleAlphaCLIP" and res["Classification"] == "recorder.new_evaluator"
+
+
+def test_launcher_forgets_reference_modules_imported_earlier(tmp_path):
+    """Called as a function from a process that has already imported a foreign `models` (e.g. a notebook kernel started in
+    the checkout): the stale module is dropped and the next import resolves to the drop-in."""
+    import importlib
+    import types
+    from camouflaged_vlm_amd import run
+    script = str(tmp_path / "s.py")
+    open(script, "w").close()
+    saved_path, saved_mods = list(sys.path), {k: v for k, v in sys.modules.items() if k.split(".")[0] in run.SHADOWED}
+    try:
+        for k in saved_mods:
+            del sys.modules[k]
+        stale = types.ModuleType("models")
+        stale.__file__ = str(tmp_path / "models" / "__init__.py")
+        sys.modules["models"] = stale
+        merged = run.arrange_sys_path(script)
+        assert merged[:3] == [cv.DROPIN_DIR, REPO, str(tmp_path)]
+        assert "models" not in sys.modules
+        m = importlib.import_module("models")
+        assert os.path.realpath(m.__file__).startswith(os.path.realpath(cv.DROPIN_DIR))
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k.split(".")[0] in run.SHADOWED]:
+            del sys.modules[k]
+        sys.modules.update(saved_mods)

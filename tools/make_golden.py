@@ -8,7 +8,7 @@ into the reference modules with ``load_state_dict(strict=True)`` (which is also 
 spec.py restates the reference's key layout exactly), and the reference's outputs are saved as
 small ``.npz`` fixtures under tests/golden/.
 
-Usage:  python tools/make_golden.py [--out tests/golden] [--demo-digest]
+Usage:  python tools/make_golden.py [--out tests/golden] [--demo-digest] [--only-demo-digest|--only-hires-digest [--images N] [--check]]
 """
 from __future__ import annotations
 
@@ -158,6 +158,11 @@ def tiny(out_dir, mods):
     tap("hs", model.mask_decoder.transformer, lambda o: o[0])
     tap("src", model.mask_decoder.transformer, lambda o: o[1])
     tap("low_res_masks", model.mask_decoder, lambda o: o[0])
+    # mask_decoder_edge.py:170,172-178: edge_embedding = embedding_maskfeature(upscaled) + edge_features (the sum is formed
+    # below from the two module outputs); hypernetwork rows actually used by mask 0: mask token 0 and the edge token
+    tap("maskfeature", model.mask_decoder.embedding_maskfeature)
+    tap("hyper_mask0", model.mask_decoder.output_hypernetworks_mlps[0])
+    tap("hyper_edge", model.mask_decoder.edge_mlp)
     tap("clip_visual", model.clip_model.image_encoder)
     tap("clip_text", model.clip_model.text_encoder)
     with torch.no_grad():
@@ -166,6 +171,7 @@ def tiny(out_dir, mods):
     masks, preds, logits, logits1 = run_reference(model, inp, clip_image, clip_mask, c.image_resolution)
     for h in hooks:
         h.remove()
+    taps["edge_emb"] = taps.pop("maskfeature") + taps["edge_features"]
     np.savez_compressed(
         os.path.join(out_dir, "tiny_cascade.npz"),
         mask_logits=masks.astype(np.float32), pred=preds.astype(np.int64), class_logits=logits.astype(np.float32),
@@ -197,25 +203,64 @@ def tokens(out_dir, mods):
     print("tokens:", tk_train.shape, tk_test.shape, "eot test", tk_test.argmax(-1)[:8])
 
 
-def demo_digest(out_dir, mods, n_images=1):
-    """G3: full demo.yaml geometry, B=1, digests only (per-stage stats + packed mask + logits)."""
+def demo_digest(out_dir, mods, n_images=16, check=False):
+    """G3: full demo.yaml geometry, B=1 per image (the reference is B=1 only), digests only.  Every array is PER IMAGE
+    (leading dimension n_images): packed mask bits, 4096 sampled mask logits (the same positions for every image),
+    class logits of both CLIP passes, predictions.  Images are `synth.make_inputs(..., batch=n)` rows 0..n-1, i.e. image i
+    does not depend on n: a run with fewer images reproduces a prefix of the committed file (--check compares that prefix).
+    bench.py times batches of 8 (images 0-7 and 8-15 alternate; rank 1 of a multi-GPU run owns 8-15)."""
     mm, ml, cm, train_names, test_names = mods
     g, c = spec.DEMO_SAM, spec.DEMO_CLIP
     model, sd, eot_train, eot_test = build_reference(mm, ml, cm, g, c, train_names, test_names)
     inp, clip_image, clip_mask = synth.make_inputs(g, c, batch=n_images)
     import time
-    t0 = time.time()
-    masks, preds, logits, logits1 = run_reference(model, inp, clip_image, clip_mask, c.image_resolution)
-    dt = time.time() - t0
     rng = np.random.default_rng(0)
-    idx = rng.integers(0, masks[0].size, size=4096)
-    np.savez_compressed(
-        os.path.join(out_dir, "demo_digest.npz"),
-        mask_bits=np.packbits(masks > 0), mask_samples=masks.reshape(n_images, -1)[:, idx], sample_idx=idx,
-        mask_stats=np.array([masks.mean(), masks.std(), masks.min(), masks.max()], np.float64),
-        pred=preds.astype(np.int64), class_logits=logits.astype(np.float32), pass1_logits=logits1.astype(np.float32),
-        eot_test=eot_test, eot_train=eot_train, ref_seconds=np.array(dt), threads=np.array(torch.get_num_threads()))
-    print("demo: %d image(s) in %.1f s; mask std %.3f; pred %s" % (n_images, dt, masks.std(), preds))
+    idx = rng.integers(0, inp.shape[2] * inp.shape[3], size=4096)
+    bits, samples, stats, preds, logits, logits1, secs = [], [], [], [], [], [], []
+    # encoder output (B,256,64,64) of the same run: the `--workload encoder` bench line (BASELINE configs[1]) is checked
+    # against these samples / channel means; the first infer_test call of run_reference is the one recorded
+    feat_idx = np.random.default_rng(2).integers(0, g.out_chans * g.grid * g.grid, size=16384)
+    feats, fsamples, fcmean = [], [], []
+    hook = model.image_encoder.register_forward_hook(
+        lambda m_, i_, o_: feats.append((o_[0] if isinstance(o_, (tuple, list)) else o_).detach().numpy().copy()))
+    for b in range(n_images):
+        t0 = time.time()
+        feats.clear()
+        m, p, s, s1 = run_reference(model, inp[b:b + 1], clip_image[b:b + 1], clip_mask[b:b + 1], c.image_resolution)
+        secs.append(time.time() - t0)
+        fsamples.append(feats[0].reshape(-1)[feat_idx].astype(np.float32))
+        fcmean.append(feats[0].mean(axis=(0, 2, 3)).astype(np.float32))
+        bits.append(np.packbits(m > 0)); samples.append(m.reshape(-1)[idx])
+        stats.append([m.mean(), m.std(), m.min(), m.max()])
+        preds.append(p[0]); logits.append(s[0]); logits1.append(s1[0])
+        print("demo: image %d in %.1f s; mask std %.3f; pred %s" % (b, secs[-1], m.std(), p), flush=True)
+    out = dict(mask_bits=np.stack(bits), mask_samples=np.stack(samples).astype(np.float32), sample_idx=idx,
+               mask_stats=np.array(stats, np.float64), pred=np.array(preds, np.int64),
+               class_logits=np.stack(logits).astype(np.float32), pass1_logits=np.stack(logits1).astype(np.float32),
+               eot_test=eot_test, eot_train=eot_train, feat_idx=feat_idx, feat_samples=np.stack(fsamples),
+               feat_channel_mean=np.stack(fcmean))
+    hook.remove()
+    path = os.path.join(out_dir, "demo_digest.npz")
+    if check:
+        _check_prefix(path, out, n_images)
+        return
+    np.savez_compressed(path, ref_seconds=np.array(secs), threads=np.array(torch.get_num_threads()), **out)
+
+
+def _check_prefix(path, out, n):
+    """--check: the arrays just produced by the reference equal the first n images of the committed file, bit for bit."""
+    with np.load(path) as z:
+        worst = 0.0
+        for k, v in out.items():
+            ref = z[k]
+            if ref.shape != v.shape:                     # per-image arrays: compare the prefix
+                ref = ref[:n]
+            d = float(np.abs(ref.astype(np.float64) - v.astype(np.float64)).max()) if v.size else 0.0
+            worst = max(worst, d)
+            print("check %-14s %-18s max abs diff %g" % (k, v.shape, d))
+    print("check: %s (first %d image(s)) -> %s" % (os.path.basename(path), n, "IDENTICAL" if worst == 0.0 else "DIFFERENT"))
+    if worst != 0.0:
+        sys.exit(1)
 
 
 def outlier_weights(sd):
@@ -255,9 +300,10 @@ def tiny_outliers(out_dir, mods):
            masks.std(), masks.min(), masks.max(), preds))
 
 
-def hires_digest(out_dir, mods):
+def hires_digest(out_dir, mods, n_images=4, check=False):
     """BASELINE configs[4] at its stated size: the reference's ImageEncoderViT *built* at 1536^2 with ViT-H width
-    (96x96 tokens, S = 9216 global attention, 191-row rel-pos tables), image 0 -> digest of the (1,256,96,96) output."""
+    (96x96 tokens, S = 9216 global attention, 191-row rel-pos tables); per image (B = 1 forwards of images 0..n-1, the
+    batch bench.py times at --geometry hires1536 --batch 4): 16384 samples of the (1,256,96,96) output + channel means."""
     import dataclasses
     import importlib
     import time
@@ -275,19 +321,30 @@ def hires_digest(out_dir, mods):
     assert ref_keys == set(mine.keys()), (sorted(ref_keys - set(mine))[:8], sorted(set(mine) - ref_keys)[:8])
     enc.load_state_dict({k: torch.from_numpy(v) for k, v in mine.items()}, strict=True)
     enc.eval()
-    inp = synth.make_inputs(g, spec.DEMO_CLIP, batch=1)[0]
-    t0 = time.time()
-    with torch.no_grad():
-        out = enc(torch.from_numpy(inp))
-    out = (out[0] if isinstance(out, (tuple, list)) else out).numpy()
-    dt = time.time() - t0
+    inp = synth.make_inputs(g, spec.DEMO_CLIP, batch=n_images)[0]
     rng = np.random.default_rng(1)
-    idx = rng.integers(0, out.size, size=16384)
-    np.savez_compressed(os.path.join(out_dir, "hires1536_digest.npz"), shape=np.array(out.shape), sample_idx=idx,
-                        samples=out.reshape(-1)[idx].astype(np.float32),
-                        stats=np.array([out.mean(), out.std(), out.min(), out.max()], np.float64),
-                        channel_mean=out.mean(axis=(0, 2, 3)).astype(np.float32), ref_seconds=np.array(dt))
-    print("hires1536: encoder output %s in %.1f s; std %.4f min %.3f max %.3f" % (out.shape, dt, out.std(), out.min(), out.max()))
+    idx = None
+    samples, stats, cmean, secs, shape = [], [], [], [], None
+    for b in range(n_images):
+        t0 = time.time()
+        with torch.no_grad():
+            o = enc(torch.from_numpy(inp[b:b + 1]))
+        o = (o[0] if isinstance(o, (tuple, list)) else o).numpy()
+        secs.append(time.time() - t0)
+        if idx is None:
+            idx, shape = rng.integers(0, o.size, size=16384), o.shape
+        samples.append(o.reshape(-1)[idx].astype(np.float32))
+        stats.append([o.mean(), o.std(), o.min(), o.max()])
+        cmean.append(o.mean(axis=(0, 2, 3)).astype(np.float32))
+        print("hires1536: image %d, encoder output %s in %.1f s; std %.4f min %.3f max %.3f" %
+              (b, o.shape, secs[-1], o.std(), o.min(), o.max()), flush=True)
+    out = dict(shape=np.array(shape), sample_idx=idx, samples=np.stack(samples), stats=np.array(stats, np.float64),
+               channel_mean=np.stack(cmean))
+    path = os.path.join(out_dir, "hires1536_digest.npz")
+    if check:
+        _check_prefix(path, out, n_images)
+        return
+    np.savez_compressed(path, ref_seconds=np.array(secs), **out)
 
 
 def n3_openai(out_dir, mods):
@@ -390,6 +447,12 @@ if __name__ == "__main__":
     ap.add_argument("--only-hires-digest", action="store_true")
     ap.add_argument("--only-n3", action="store_true")
     ap.add_argument("--skip-tiny", action="store_true")
+    ap.add_argument("--only-demo-digest", action="store_true")
+    ap.add_argument("--images", type=int, default=None,
+                    help="digest runs: number of images (default 16 for the demo digest, 4 for the 1536^2 digest)")
+    ap.add_argument("--check", action="store_true",
+                    help="digest runs: do not write; compare the reference's fresh output with the first --images images "
+                         "of the committed file, bit for bit")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     mods = install_reference()
@@ -403,11 +466,14 @@ if __name__ == "__main__":
         n3_openai(args.out, mods)
         sys.exit(0)
     if args.only_hires_digest:
-        hires_digest(args.out, mods)
+        hires_digest(args.out, mods, args.images or 4, args.check)
+        sys.exit(0)
+    if args.only_demo_digest:
+        demo_digest(args.out, mods, args.images or 16, args.check)
         sys.exit(0)
     tokens(args.out, mods)
     if not args.skip_tiny:
         tiny(args.out, mods)
     sam_plain(args.out, mods)
     if args.demo_digest:
-        demo_digest(args.out, mods)
+        demo_digest(args.out, mods, args.images or 16, args.check)
