@@ -9,17 +9,28 @@ N > 1 without RANK in the environment: this process starts N ranks itself (`pyth
 as a child, before anything here has touched the GPU), relays rank 0's JSON line and exits with the child's
 code.  Under a launcher (RANK / WORLD_SIZE set) it is one of the ranks.
 
-A step = one cascade pass over one resident batch of 8 images per GPU.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one resident batch (8 images per GPU by default).  Two DIFFERENT batches alternate
+from step to step (images [0,B) and [B,2B) of the rank's share), so that a cross-batch hazard of the pipelined loop could
+not hide behind identical inputs.  Rank 0 prints ONE JSON line.
 `value`       : whole-job images/s over the K timed steps (wall clock, barrier + synchronize on both sides, max over ranks);
                 `step_ms` holds the median / p10 / p90 of the per-step HIP-event durations of the same K steps.
-`parity`      : the outputs of the LAST TIMED step are checked: all finite; image 0 of rank 0 against the digest of the
-                reference's own output (tests/golden/demo_digest.npz): IoU >= 0.999, |mask| and |class logits| <= 1e-3.
+`parity`      : the outputs of the LAST TWO TIMED steps (one per batch) are checked: all finite; EVERY image the reference
+                digest holds (tests/golden/demo_digest.npz: 16 images, each a B = 1 forward of the reference itself) against it:
+                IoU >= 0.999, |mask| and |class logits| <= 1e-3, same prediction.
 `bank_check`  : N > 1: the all-gathered text bank equals, bit for bit, the bank every rank computes alone.
 `roofline`    : the dominant kernel (the split-half MFMA GEMM): algorithmic FLOPs (2*M*N*K per launch) divided by its
-                HIP-event time over an instrumented repeat of the timed steps; `secondary` holds the two ViT-H attention
+                HIP-event time over an instrumented repeat of the timed steps; `secondary` holds the ViT-H attention
                 kernels measured the same way (algorithmic 4*S^2*hd per head).
 `cpu_baseline`: the CPU oracle (oracle/cvlm_oracle.py, a port of the reference forward) timed on the host cores on a
-                bounded sample (rank 0, N = 1 only): 1 warm-up + 3 images on the box's 16-core share.
+                bounded sample (rank 0, N = 1 only).
+
+Other lines (same JSON shape, `config.workload` says which):
+  --workload encoder                                  BASELINE configs[1]: SAM ViT-H image encoder only, batch 8
+  --workload encoder --geometry hires1536 --batch 4   BASELINE configs[4]: encoder built at 1536^2, batch 4
+  --surface dropin [--batch 1|8]                      the reference's own call pattern (demo.py:110-122,
+        test_ovcos_maskdecoder_edge.py:89-113, DataLoader batch_size=1): models.make(cfg).cuda() -> load_mapleAlphaCLIP ->
+        load_state_dict(strict) -> per step: infer_test -> torch.sigmoid -> F.interpolate -> clip_model, one host
+        synchronisation per step (the scripts read the prediction back every image).
 """
 from __future__ import annotations
 
@@ -29,6 +40,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -37,34 +49,112 @@ if REPO not in sys.path:
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: BF16/F16 dense ~2.5 PF
 WORK_TFLOP_PER_IMAGE = 6.461               # algorithmic work per image, text bank cached
-TOL = 1e-3                                 # BASELINE.json north_star: 1e-3 abs vs the fp32 CPU forward, IoU >= 0.999
+ENCODER_TFLOP_PER_IMAGE = {1024: 5.681, 1536: 13.712}
 # Measured on this part (tools/power_roofline.py, profiles/r02_power_roofline.log): an MFMA-only loop (16x16x32 f16, random
 # operands, every CU) settles at 1.88 PF at the 1400-W socket cap (sclk 1.95 GHz of 2.4): what the matrix pipe can sustain.
 MFMA_F16_POWER_ROOFLINE_TFLOPS = 1880.0
+TRAFFIC_FILES = ("r03_gemm_traffic.json", "r02_gemm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest first
+
+
+def under_profiler() -> bool:
+    """rocprofv3 preloads its tool library (it initialises the GPU): no child process may be started from here then."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or "roctx" in pre or any(k.startswith(("ROCP", "ROCPROF", "ROCPROFILER")) for k in os.environ)
 
 
 class PowerSampler:
-    """Socket power and shader clock during the timed region: a CHILD process polls rocm-smi (this process only reads its
-    output afterwards).  Everything is optional: no rocm-smi, no samples, no field."""
+    """Socket power and shader clock during the timed region.  Preferred source: the amdgpu hwmon / sysfs files, read by a
+    thread of THIS process (no child, nothing to leak, safe under a profiler).  Fallback: a child process polling rocm-smi
+    with a scrubbed environment, never under a profiler, which ends by itself when this process goes away.
+    Everything is optional: no source, no samples, no field."""
 
-    def __init__(self):
+    def __init__(self, device_index: int = 0, enabled: bool = True, pci: str = ""):
+        self.enabled = enabled
+        self.dev = device_index
+        self.pci = pci.lower()
         self.proc, self.path = None, None
+        self.thread, self.stop_flag, self.samples = None, threading.Event(), []
+        self.power_file, self.sclk_file = None, None
+
+    def _find_sysfs(self):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        # keep amdgpu cards only, in card order; the rank's GPU is the device_index-th of them
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "power1_average")) or os.path.exists(os.path.join(c, "power1_input"))]
+        # the host's sysfs lists every GPU of the node, visible to this process or not: pick ours by PCI address
+        mine = [c for c in cards if self.pci and os.path.basename(os.path.realpath(os.path.join(os.path.dirname(os.path.dirname(c))))).lower() == self.pci]
+        if mine:
+            hw = mine[0]
+        elif not self.pci and self.dev < len(cards):
+            hw = cards[self.dev]
+        else:
+            return False
+        for name in ("power1_average", "power1_input"):
+            f = os.path.join(hw, name)
+            if os.path.exists(f):
+                self.power_file = f
+                break
+        f = os.path.join(hw, "freq1_input")
+        self.sclk_file = f if os.path.exists(f) else None
+        try:
+            with open(self.power_file) as fh:
+                float(fh.read().strip())
+        except (OSError, ValueError, TypeError):
+            self.power_file = None
+        return self.power_file is not None
+
+    def _poll(self):
+        while not self.stop_flag.is_set():
+            try:
+                with open(self.power_file) as fh:
+                    w = float(fh.read().strip()) * 1e-6
+                mhz = None
+                if self.sclk_file:
+                    with open(self.sclk_file) as fh:
+                        mhz = float(fh.read().strip()) * 1e-6
+                self.samples.append((time.time(), w, mhz))
+            except (OSError, ValueError):
+                pass
+            self.stop_flag.wait(0.25)
 
     def start(self):
+        if not self.enabled:
+            return
+        if self._find_sysfs():
+            self.thread = threading.Thread(target=self._poll, daemon=True)
+            self.thread.start()
+            return
         import shutil, tempfile
-        if shutil.which("rocm-smi") is None:
+        if under_profiler() or shutil.which("rocm-smi") is None:
             return
         fd, self.path = tempfile.mkstemp(prefix="cvlm_power_", suffix=".log")
         os.close(fd)
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS"))}
         try:
+            # ends by itself when this process is gone (kill -0 $PPID) or after 10 minutes, whatever happens here
             self.proc = subprocess.Popen(
-                ["bash", "-c", "while true; do echo STAMP $(date +%s.%N); rocm-smi --showpower --showclocks; sleep 0.25; done"],
-                stdout=open(self.path, "w"), stderr=subprocess.DEVNULL, start_new_session=True)
+                ["bash", "-c", "n=0; while kill -0 $PPID 2>/dev/null && [ $n -lt 2400 ]; do echo STAMP $(date +%s.%N); "
+                               "rocm-smi --showpower --showclocks; sleep 0.25; n=$((n+1)); done"],
+                stdout=open(self.path, "w"), stderr=subprocess.DEVNULL, start_new_session=True, env=env)
         except OSError:
             self.proc = None
 
-    def stop(self, t0: float, t1: float, device_index: int = 0):
+    def stop(self, t0: float = 0.0, t1: float = float("inf")):
         import re, signal
+        if self.thread is not None:
+            self.stop_flag.set()
+            self.thread.join(timeout=2)
+            self.thread = None
+            sel = [s for s in self.samples if t0 <= s[0] <= t1]
+            if not sel:
+                return None
+            pw = [s[1] for s in sel]
+            sc = [s[2] for s in sel if s[2] is not None]
+            return {"socket_w_mean": round(sum(pw) / len(pw), 1), "socket_w_max": round(max(pw), 1),
+                    "sclk_mhz_mean": round(sum(sc) / len(sc)) if sc else None, "sclk_mhz_max_of_part": 2400, "samples": len(pw),
+                    "source": self.power_file,
+                    "note": "amdgpu hwmon (power1_input / freq1_input of this GPU's PCI device) read by a thread of this process "
+                            "during the timed steps"}
         if self.proc is None:
             return None
         try:
@@ -72,6 +162,7 @@ class PowerSampler:
             self.proc.wait(timeout=5)
         except Exception:
             pass
+        self.proc = None
         try:
             with open(self.path) as f:
                 text = f.read()
@@ -86,8 +177,8 @@ class PowerSampler:
                 continue
             if not (t0 <= ts <= t1):
                 continue
-            p = re.search(r"GPU\[%d\]\s*: .*Power \(W\): ([0-9.]+)" % device_index, chunk)
-            c = re.search(r"GPU\[%d\]\s*: sclk clock level: \d+: \((\d+)Mhz\)" % device_index, chunk)
+            p = re.search(r"GPU\[%d\]\s*: .*Power \(W\): ([0-9.]+)" % self.dev, chunk)
+            c = re.search(r"GPU\[%d\]\s*: sclk clock level: \d+: \((\d+)Mhz\)" % self.dev, chunk)
             if p and c:
                 pw.append(float(p.group(1)))
                 sc.append(int(c.group(1)))
@@ -108,6 +199,9 @@ def parse():
     ap.add_argument("--geometry", default="demo", choices=["demo", "tiny", "hires1536"])
     ap.add_argument("--workload", default="cascade", choices=["cascade", "encoder"],
                     help="encoder = SAM ViT-H image encoder only (BASELINE configs[1] / [4] with --geometry hires1536)")
+    ap.add_argument("--surface", default="engine", choices=["engine", "dropin"],
+                    help="dropin = the reference's call surface and call pattern (models.make / infer_test / torch sigmoid + "
+                         "interpolate / clip_model, one synchronisation per step), cascade workload only")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run CLIP pass 1 after the SAM encoder instead of on a side stream beneath it (profiling runs: "
                          "co-running kernels stretch each other's durations)")
@@ -116,6 +210,7 @@ def parse():
     ap.add_argument("--single-device", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not sample socket power / clock during the timed steps")
     return ap.parse_args()
 
 
@@ -153,6 +248,103 @@ def cpu_model() -> str:
     return "unknown"
 
 
+DTYPE_NAMES = {"exact": "f32-grade (3x f16 split MFMA, f32 accumulate)", "mixed": "f32-grade GEMM/QK, f16 PV",
+               "fast": "f16 operands, f32 accumulate"}
+
+
+class Roofline:
+    """Instrumented repeat of the step: every cvlm_gemm / ViT-H cvlm_attention launch between two HIP events on the stream it
+    is launched on (torch's current stream is the stream hip.py hands to the launchers)."""
+
+    def __init__(self, torch, hip, split: int):
+        self.torch, self.hip, self.split = torch, hip, split
+        self.records, self.arecs = [], {"global": [], "window": []}
+
+    def __enter__(self):
+        torch, hip = self.torch, self.hip
+        self.orig, self.orig_attn = hip.gemm, hip.attention
+        orig, orig_attn, records, arecs = self.orig, self.orig_attn, self.records, self.arecs
+
+        def timed_gemm(a, w, M, N, K, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(a, w, M, N, K, **kw)
+            e1.record()
+            records.append((2.0 * M * N * K * kw.get("batch", 1), e0, e1))
+
+        def timed_attn(qkv, o, Bn, S, heads, hd, **kw):
+            mode = kw.get("mode", 0)
+            if mode not in (1, 2):
+                return orig_attn(qkv, o, Bn, S, heads, hd, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_attn(qkv, o, Bn, S, heads, hd, **kw)
+            e1.record()
+            if mode == 1:                                   # global: every query x every key
+                fl = 4.0 * S * S * hd * heads * Bn
+            else:                                           # 14x14 windows of the padded map (image_encoder.py:507-530)
+                w = kw["window"]
+                G = kw["grid"]
+                nw = -(-G // w)
+                fl = 4.0 * (w * w) ** 2 * hd * heads * Bn * nw * nw
+            arecs["global" if mode == 1 else "window"].append((fl, e0, e1, S))
+
+        hip.gemm, hip.attention = timed_gemm, timed_attn
+        return self
+
+    def __exit__(self, *exc):
+        self.hip.gemm, self.hip.attention = self.orig, self.orig_attn
+        return False
+
+    def result(self, nrep: int, step_seconds: float, traffic_ok: bool) -> dict:
+        records, arecs = self.records, self.arecs
+        traffic, tnote = None, None
+        for tname in TRAFFIC_FILES:
+            tfile = os.path.join(REPO, "profiles", tname)
+            if traffic_ok and os.path.exists(tfile):
+                with open(tfile) as f:
+                    traffic = round(json.load(f)["traffic_bytes_per_launch"])
+                tnote = ("REPLAYED, not measured in this run: HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE "
+                         f"(x2 gfx950 correction) and WRITE_SIZE passes of the default command (profiles/{tname})")
+                break
+        flops = sum(r[0] for r in records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in records)
+        achieved = flops / (ms * 1e-3) / 1e12
+        secondary = []
+        for name in ("global", "window"):
+            rs = arecs[name]
+            if not rs:
+                continue
+            S = rs[0][3]
+            kern = {"global": "attn_g64pair_kernel (ViT-H global attention, 64x64 map)" if S == 4096 else
+                              f"global-attention kernel, S = {S} ({int(S ** 0.5)}x{int(S ** 0.5)} map)",
+                    "window": "attn_win14_kernel (ViT-H 14x14 window attention)"}[name]
+            f_, m_ = sum(r[0] for r in rs), sum(r[1].elapsed_time(r[2]) for r in rs)
+            tf = f_ / (m_ * 1e-3) / 1e12
+            issued_factor = self.split * (1.0 + 0.5 * (96.0 / 80.0 - 1.0)) if self.split == 3 else 1.0
+            secondary.append({"kernel": kern, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+                              "issued": round(tf * issued_factor, 1), "frac_issued": round(tf * issued_factor / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+                              "launches": len(rs), "avg_launch_us": round(1e3 * m_ / len(rs), 2),
+                              "algorithmic_gflop_per_launch": round(f_ / len(rs) / 1e9, 3),
+                              "note": "achieved / frac: algorithmic FLOPs (4*S^2*hd per head, SURVEY.md §8d); issued: the MFMA flops the "
+                                      "exact mode executes for them (3 f16 products per multiply; P.V on head dim 80 padded to 96)"})
+        return {"kernel": "gemm_nt_kernel<split=%d>" % self.split, "bound": "mfma",
+                "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
+                "launches": len(records), "avg_launch_us": round(1e3 * ms / len(records), 2),
+                "algorithmic_gflop_per_launch": round(flops / len(records) / 1e9, 3),
+                "gemm_share_of_step": round(ms * 1e-3 / nrep / step_seconds, 3),
+                "issued": round(achieved * self.split, 2),
+                "issued_note": "MFMA flops issued: the exact mode forms every product from 3 f16 MFMAs (hi.hi + lo.hi + hi.lo)",
+                "power_roofline": {"peak": MFMA_F16_POWER_ROOFLINE_TFLOPS, "unit": "TFLOP/s issued",
+                                   "frac_issued": round(achieved * self.split / MFMA_F16_POWER_ROOFLINE_TFLOPS, 4),
+                                   "note": "what an MFMA-only loop sustains at the 1400-W socket cap with random operands "
+                                           "(profiles/r02_power_roofline.log); the GEMM itself runs AT the cap: its energy per "
+                                           "launch = matrix pipe 51 % + L2->LDS DMA 26 % + idle 21 % (DESIGN.md section 6)"},
+                "secondary": secondary}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -177,10 +369,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from camouflaged_vlm_amd import hip, host, spec, synth
+    from camouflaged_vlm_amd import digest, hip, host, spec, synth
     from camouflaged_vlm_amd.engine import Cascade, Precision
     import camouflaged_vlm_amd as cv
-    sys.path.insert(0, cv.DROPIN_DIR)
+    if cv.DROPIN_DIR not in sys.path:
+        sys.path.insert(0, cv.DROPIN_DIR)
     from cocotrainers.mapleAlphaCLIP import gather_text_features
 
     g, c = (spec.DEMO_SAM, spec.DEMO_CLIP) if args.geometry in ("demo", "hires1536") else (spec.TINY_SAM, spec.TINY_CLIP)
@@ -188,37 +381,288 @@ def main():
         import dataclasses
         g = dataclasses.replace(g, inp_size=1536)            # model *built* at 1536 (pos_embed 96^2, rel_pos 191x80)
         args.workload = "encoder"
+    if args.surface == "dropin" and (args.workload != "cascade" or world > 1):
+        sys.exit("--surface dropin: cascade workload on one GPU")
     B = args.batch
+    prec = Precision.named(args.precision)
     t0 = time.time()
     sd_np = synth.make_full_state_dict(g, c)
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    # the rank's share: two batches of B images; the reference digests hold images 0..15 (demo) / 0..3 (1536^2)
+    first = rank * 2 * B
+    ids = [list(range(first, first + B)), list(range(first + B, first + 2 * B))]
+    images = synth.make_inputs(g, c, batch=2 * B, index0=first)
+    batches = [tuple(torch.from_numpy(np.ascontiguousarray(t[k * B:(k + 1) * B])).to(dev) for t in images) for k in range(2)]
+    try:
+        pr_ = torch.cuda.get_device_properties(dev)
+        pci = "%04x:%02x:%02x.0" % (pr_.pci_domain_id, pr_.pci_bus_id, pr_.pci_device_id)
+    except Exception:
+        pci = ""
+    sampler = PowerSampler(local_rank, enabled=(rank == 0 and not args.no_power), pci=pci)
+
+    def timed_loop(step, sync_each: bool = False, flush=lambda: None):
+        """W warm-up steps, then K timed steps between barrier + synchronize; returns (elapsed, max-over-ranks elapsed,
+        per-step ms, outputs of the last two steps as [(batch index, output)], power)."""
+        for i in range(args.warmup):
+            step(i % 2)
+            if sync_each:
+                torch.cuda.synchronize()
+        flush()                                              # nothing owed from the warm-up when the clock starts
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        outs = []
+        sampler.start()
+        wall0 = time.time()
+        try:
+            t1 = time.perf_counter()
+            marks[0].record()
+            for i in range(args.steps):
+                o = step(i % 2)
+                marks[i + 1].record()
+                if sync_each:
+                    torch.cuda.synchronize()
+                outs.append((i % 2, o))
+                outs = outs[-2:]
+            flush()                                          # the pipelined loop's last stage 2: K steps = K full cascades
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            mine = time.perf_counter() - t1
+        finally:
+            power = sampler.stop(wall0 + 0.3, time.time())
+        total = mine
+        if world > 1:
+            tmax = torch.tensor([mine], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            total = float(tmax.item())
+        step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        return mine, total, step_ms, outs, power
+
+    def rank_rates(mine: float, images_per_step: int):
+        """images/s of every rank over its own timed loop (stragglers show as a low minimum)."""
+        r = images_per_step * args.steps / mine
+        if world == 1:
+            return {"min": round(r, 3), "max": round(r, 3)}
+        t = torch.tensor([r], dtype=torch.float64, device=dev)
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return {"min": round(float(lo.item()), 3), "max": round(float(hi.item()), 3)}
+
+    def step_block(step_ms):
+        return {"median": round(percentile(step_ms, 0.5), 3), "p10": round(percentile(step_ms, 0.1), 3),
+                "p90": round(percentile(step_ms, 0.9), 3), "n": len(step_ms),
+                "note": "per-step HIP-event durations of the timed steps on rank 0"}
+
+    def finish(line, ok: bool):
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()                                   # rank 0 ran the instrumented roofline repeat meanwhile
+            dist.destroy_process_group()
+        if not ok:
+            sys.exit(3)
+
+    def all_ranks(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        okt = torch.tensor([int(ok)], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        return bool(int(okt.item()))
+
+    # ==================================================================================================================
+    # SAM ViT-H image encoder only (BASELINE configs[1]; configs[4] at 1536^2)
+    # ==================================================================================================================
     if args.workload == "encoder":
         from camouflaged_vlm_amd.engine import SamEncoder
-        enc = SamEncoder(sd, g, dev, Precision.named(args.precision))
-        inp = torch.from_numpy(synth.make_inputs(g, c, batch=B, index0=rank * B)[0]).to(dev)
-        for _ in range(args.warmup):
-            enc.forward(inp)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            out = enc.forward(inp)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
-        finite = bool(torch.isfinite(out).all())
-        tf_img = {1024: 5.681, 1536: 13.712}.get(g.inp_size)
-        print(json.dumps({"metric": f"images/sec, SAM ViT-H image encoder only at {g.inp_size}x{g.inp_size}",
-                          "value": round(B * args.steps / el, 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-                          "config": {"workload": f"SAM ViT-H encoder only, batch {B}, {g.inp_size}^2", "precision": args.precision},
-                          "outputs_finite": finite,
-                          "achieved_tflops_algorithmic": round(B * args.steps / el * tf_img, 1) if tf_img else None}))
-        if not finite:
-            sys.exit(3)
-        return
+        enc = SamEncoder(sd, g, dev, prec)
+        setup_s = time.time() - t0
+        names = ["features0", "features1"]
+
+        def step(k):
+            return enc.forward(batches[k][0], out_name=names[k])
+        mine, elapsed, step_ms, outs, power = timed_loop(step)
+        value = world * B * args.steps / elapsed
+        finite = all(bool(torch.isfinite(o).all()) for _, o in outs)
+        parity = {"outputs_finite": finite, "parity_checked": False, "ok": finite}
+        dname = {"demo": "demo_digest.npz", "hires1536": "hires1536_digest.npz"}.get(args.geometry)
+        if dname and os.path.exists(digest.golden_path(dname)):
+            dg = digest.load(digest.golden_path(dname))
+            chk = digest.check_demo_features if args.geometry == "demo" else digest.check_hires_features
+            res = [chk(o, g.grid, dg, ids[k]) for k, o in outs]
+            checked = sorted(set(i for r in res for i in r["checked_images"]))
+            if checked:
+                parity.update({"parity_checked": True, "checked_images": checked,
+                               "reference": f"tests/golden/{dname}: the reference's own encoder output per image (samples + channel means)",
+                               "max_abs_feature_err": max(r.get("max_abs_feature_err", 0.0) for r in res),
+                               "max_abs_channel_mean_err": max(r.get("max_abs_channel_mean_err", 0.0) for r in res),
+                               "tolerance": digest.TOL, "ok": bool(finite and all(r["ok"] for r in res))})
+        parity["gemm_handoff_errors"] = enc.ws.gemm_errors()
+        parity["ok"] = bool(parity["ok"] and parity["gemm_handoff_errors"] == 0)
+        parity["all_ranks_ok"] = all_ranks(parity["ok"])
+        rates = rank_rates(mine, B)
+        roofline = None
+        if not args.no_roofline and rank == 0:
+            nrep = max(1, min(args.steps, 2))
+            with Roofline(torch, hip, prec.gemm) as rf:
+                for i in range(nrep):
+                    step(i % 2)
+                torch.cuda.synchronize()
+            roofline = rf.result(nrep, mine / args.steps, traffic_ok=False)
+        cpu = None
+        if not args.no_cpu_baseline and rank == 0 and world == 1:
+            from oracle import cvlm_oracle as O
+            host_cores = os.cpu_count() or 1
+            torch.set_num_threads(min(16, host_cores))
+            osd = O.to_torch_sd(sd_np)
+            n_warm, n_img = (1, 1) if g.inp_size <= 1024 else (0, 1)     # 1536^2: one image is 40-90 s of CPU work
+            times = []
+            with torch.no_grad():
+                for i in range(n_warm + n_img):
+                    tc = time.perf_counter()
+                    O.sam_encoder(batches[0][0][i:i + 1].cpu(), osd, g)
+                    times.append(time.perf_counter() - tc)
+            s_img = sum(times[n_warm:]) / n_img
+            cpu = {"value": round(1.0 / s_img, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                   "sample": f"{n_warm} warm-up + {n_img} image(s), B=1 SAM encoder forward of the fp32 torch-CPU oracle: "
+                             f"{s_img:.2f} s/image", "cpu_model": cpu_model(), "host_cores": host_cores}
+        tf_img = ENCODER_TFLOP_PER_IMAGE.get(g.inp_size)
+        line = {"metric": f"images/sec, SAM ViT-H image encoder only at {g.inp_size}x{g.inp_size}",
+                "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
+                "config": {"workload": f"SAM-Adapter ViT-H image encoder only, batch {B}, {g.inp_size}^2 "
+                                       f"(BASELINE configs[{1 if g.inp_size == 1024 else 4}])" if args.geometry != "tiny" else "tiny geometry (debug)",
+                           "images_per_gpu_per_step": B, "global_batch": B * world, "precision": args.precision,
+                           "parallelism": f"dp{world} (images sharded)", "setup_seconds": round(setup_s, 1)},
+                "step_ms": step_block(step_ms), "images_per_s_per_gpu": round(value / world, 3), "images_per_s_per_rank": rates,
+                "achieved_tflops_algorithmic": round(value * tf_img, 1) if tf_img and args.geometry != "tiny" else None,
+                "parity": parity, "power": power, "roofline": roofline, "cpu_baseline": cpu}
+        return finish(line, parity["all_ranks_ok"])
+
+    # ==================================================================================================================
+    # the reference's call surface and call pattern (demo.py:78-122; test_ovcos_maskdecoder_edge.py:68-113, batch_size=1)
+    # ==================================================================================================================
+    if args.surface == "dropin":
+        import torch.nn.functional as F
+        import models
+        from cocotrainers.mapleAlphaCLIP import CustomCLIP
+        if args.no_overlap:
+            os.environ["CVLM_OVERLAP_CLIP"] = "0"
+        os.environ["CVLM_PRECISION"] = args.precision
+        consts = host.ovcamo_constants()
+        eot_te = host.eot_for_classes(consts["names_test"].tolist())[:c.n_cls_test] if args.geometry == "demo" else spec.default_eot(c, "test")
+        eot_tr = host.eot_for_classes(consts["names_train"].tolist())[:c.n_cls_train] if args.geometry == "demo" else spec.default_eot(c, "train")
+        enc_mode = dict(name="sam", img_size=g.inp_size, mlp_ratio=g.mlp_ratio, patch_size=g.patch_size, qkv_bias=True,
+                        use_rel_pos=True, window_size=g.window_size, out_chans=g.out_chans, scale_factor=32, input_type="fft",
+                        freq_nums=0.25, prompt_type="highpass", prompt_embed_dim=g.prompt_embed_dim, tuning_stage=1234,
+                        handcrafted_tune=True, embedding_tune=True, adaptor="adaptor", embed_dim=g.embed_dim, depth=g.depth,
+                        num_heads=g.num_heads, global_attn_indexes=list(g.global_attn_indexes))   # configs/demo.yaml `model.args`
+        maple = CustomCLIP(geometry=c, eot_train=eot_tr, eot_test=eot_te)
+        model = models.make({"name": "sam_maskdecoder_edge",
+                             "args": {"inp_size": g.inp_size, "loss": "iou", "encoder_mode": enc_mode}}).cuda()   # demo.py:84
+        model.train_text_features = model.train_text_features[:c.n_cls_train]
+        model.test_text_features = model.test_text_features[:c.n_cls_test]
+        model.load_mapleAlphaCLIP(maple)                                                                         # demo.py:85
+        model.load_state_dict(sd, strict=True)                                                                   # demo.py:88
+        model.eval()
+        # every image of the reference digest takes its turn: 16 // B different batches
+        nb = max(1, 16 // B) if args.geometry == "demo" else 2
+        allimg = synth.make_inputs(g, c, batch=nb * B)
+        dbatches = [tuple(torch.from_numpy(np.ascontiguousarray(t[k * B:(k + 1) * B])).to(dev) for t in allimg) for k in range(nb)]
+        R = c.image_resolution
+        seen = {}
+
+        def one(k):
+            inp, clip_image, clip_mask = dbatches[k]
+            pred_mask = model.infer_test(inp, clip_image, clip_mask)                                             # demo.py:116
+            prob = torch.sigmoid(pred_mask)                                                                      # demo.py:117
+            alpha = F.interpolate(prob, (R, R), mode="bilinear", align_corners=False)                          # demo.py:120
+            _, _, pred_1, score = model.clip_model(clip_image, alpha, train=False)                               # demo.py:122
+            return pred_mask, pred_1, score
+
+        with torch.no_grad():
+            t_first = time.perf_counter()
+            one(0)
+            torch.cuda.synchronize()
+            first_call_s = time.perf_counter() - t_first          # packs the weights, encodes the text bank once
+            setup_s = time.time() - t0
+            for i in range(args.warmup):
+                one(i % nb)
+                torch.cuda.synchronize()
+            marks = []
+            sampler.start()
+            wall0 = time.time()
+            try:
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    ts = time.perf_counter()
+                    o = one(i % nb)
+                    torch.cuda.synchronize()                      # the scripts read pred_1 / the mask back for every image
+                    marks.append(1e3 * (time.perf_counter() - ts))
+                    seen[i % nb] = o
+                elapsed = time.perf_counter() - t1
+            finally:
+                power = sampler.stop(wall0 + 0.3, time.time())
+        value = B * args.steps / elapsed
+        finite = all(bool(torch.isfinite(o[0]).all()) and bool(torch.isfinite(o[2]).all()) for o in seen.values())
+        parity = {"outputs_finite": finite, "parity_checked": False, "ok": finite}
+        if args.geometry == "demo" and os.path.exists(digest.golden_path("demo_digest.npz")):
+            dg = digest.load(digest.golden_path("demo_digest.npz"))
+            res = [digest.check_cascade(o[0], o[1], o[2], dg, list(range(k * B, (k + 1) * B))) for k, o in sorted(seen.items())]
+            checked = sorted(set(i for r in res for i in r["checked_images"]))
+            parity.update({"parity_checked": True, "checked_images": checked,
+                           "reference": "tests/golden/demo_digest.npz: the reference's own output per image (B = 1 forwards)",
+                           "min_mask_iou": round(min(r["min_iou"] for r in res), 6),
+                           "max_abs_mask_err": max(r["max_abs_mask_err"] for r in res),
+                           "max_abs_class_logit_err": max(r["max_abs_class_logit_err"] for r in res),
+                           "pred_equal": all(r["pred_equal"] for r in res), "tolerance": digest.TOL,
+                           "ok": bool(finite and all(r["ok"] for r in res))})
+        cas = model.cascade()
+        parity["gemm_handoff_errors"] = sum(e.ws.gemm_errors() for e in (cas, cas.encoder, cas.decoder, cas.clip))
+        parity["ok"] = bool(parity["ok"] and parity["gemm_handoff_errors"] == 0)
+        roofline = None
+        if not args.no_roofline:
+            nrep = max(1, min(args.steps, 2))
+            was = cas.overlap_clip
+            cas.overlap_clip = False
+            try:
+                with Roofline(torch, hip, cas.prec.gemm) as rf, torch.no_grad():
+                    for i in range(nrep):
+                        one(i % nb)
+                    torch.cuda.synchronize()
+            finally:
+                cas.overlap_clip = was
+            roofline = rf.result(nrep, elapsed / args.steps, traffic_ok=False)
+        line = {"metric": "images/sec at 1024x1024 (SAM-ViT-H + CLIP ViT-L/14), full cascade through the reference's call surface",
+                "value": round(value, 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
+                "config": {"workload": f"drop-in surface, batch {B}: models.make(cfg).cuda() -> load_mapleAlphaCLIP -> load_state_dict(strict) "
+                                       "-> per step infer_test -> torch.sigmoid -> F.interpolate(336) -> clip_model, one "
+                                       "torch.cuda.synchronize() per step (demo.py:110-122; BASELINE configs[0] call pattern on the GPU)"
+                           if args.geometry == "demo" else "tiny geometry (debug)",
+                           "images_per_step": B, "precision": args.precision, "clip_pass1_overlap": bool(cas.overlap_clip),
+                           "first_call_seconds": round(first_call_s, 2), "setup_seconds": round(setup_s, 1),
+                           "distinct_batches": nb},
+                "latency_ms_per_step": {"median": round(percentile(marks, 0.5), 3), "p10": round(percentile(marks, 0.1), 3),
+                                        "p90": round(percentile(marks, 0.9), 3), "n": len(marks),
+                                        "note": "host wall clock from the call of infer_test to the end of the synchronize after clip_model"},
+                "latency_ms_per_image": round(percentile(marks, 0.5) / B, 3),
+                "achieved_tflops_algorithmic": round(value * WORK_TFLOP_PER_IMAGE, 1) if args.geometry == "demo" else None,
+                "parity": parity, "power": power, "roofline": roofline, "cpu_baseline": None}
+        return finish(line, parity["ok"])
+
+    # ==================================================================================================================
+    # full cascade, engine level, pipelined serving loop (the headline)
+    # ==================================================================================================================
     if args.no_overlap:
         os.environ["CVLM_OVERLAP_CLIP"] = "0"
-    cas = Cascade(sd, g, c, dev, Precision.named(args.precision))
+    cas = Cascade(sd, g, c, dev, prec)
     eot = host.eot_for_classes(host.ovcamo_constants()["names_test"].tolist())[:c.n_cls_test] \
         if args.geometry == "demo" else spec.default_eot(c, "test")
     bank = torch.from_numpy(host.ovcamo_constants()["bank_test"][:c.n_cls_test]).float()
@@ -236,154 +680,58 @@ def main():
         bank_check = {"bit_identical_to_single_rank_bank_on_every_rank": bool(int(same.item())),
                       "max_abs_diff_rank0": float((alone - tf).abs().max())}
     cas.clip.set_text_bank(tf, bank, "test")
-    inp, ci, cm = synth.make_inputs(g, c, batch=B, index0=rank * B)       # each rank: its own 8 images
-    inp, ci, cm = (torch.from_numpy(t).to(dev) for t in (inp, ci, cm))
     setup_s = time.time() - t0
 
-    def step():
+    def step(k):
         # serving loop: batch i's stage 2 (on the side stream) runs under batch i+1's SAM encoder; everything is
         # complete at the synchronize() that closes the timed region
-        return cas.cascade(inp, ci, cm, pipelined=True)
+        return cas.cascade(*batches[k], pipelined=True)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    sampler = PowerSampler()
-    if rank == 0:
-        sampler.start()
-    wall0 = time.time()
-    t1 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        out = step()
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t1
-    power = sampler.stop(wall0 + 0.3, time.time(), local_rank) if rank == 0 else None
-    my_elapsed = elapsed
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    mine, elapsed, step_ms, outs, power = timed_loop(step, flush=cas.flush)
     value = world * B * args.steps / elapsed
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
 
-    # ---- parity of the timed output (last timed step): finite everywhere, image 0 of rank 0 vs the reference digest
-    masks, pred, logits = out
-    finite = bool(torch.isfinite(masks).all()) and bool(torch.isfinite(logits).all())
-    parity = {"outputs_finite": finite}
-    dpath = os.path.join(REPO, "tests", "golden", "demo_digest.npz")
-    if args.geometry == "demo" and rank == 0 and os.path.exists(dpath):
-        with np.load(dpath) as z:
-            dg = {k: z[k] for k in z.files}
-        m = masks[0:1].cpu().numpy()
-        ref_bits = np.unpackbits(dg["mask_bits"])[:m.size].reshape(m.shape).astype(bool)
-        inter, union = float(((m > 0) & ref_bits).sum()), float(((m > 0) | ref_bits).sum())
-        e_mask = float(np.abs(m.reshape(1, -1)[:, dg["sample_idx"]] - dg["mask_samples"]).max())
-        e_log = float(np.abs(logits[0:1].cpu().numpy() - dg["class_logits"]).max())
-        ok = finite and inter / max(union, 1.0) >= 0.999 and e_mask <= TOL and e_log <= TOL and \
-            pred[0:1].cpu().tolist() == dg["pred"].tolist()
-        parity.update({"parity_checked": True, "reference": "tests/golden/demo_digest.npz (reference's own output, image 0)",
-                       "mask_iou": round(inter / max(union, 1.0), 6), "max_abs_mask_err": e_mask,
-                       "max_abs_class_logit_err": e_log, "pred_equal": pred[0:1].cpu().tolist() == dg["pred"].tolist(),
-                       "tolerance": TOL, "ok": ok})
-    else:
-        parity.update({"parity_checked": False, "ok": finite})
+    # ---- parity of the timed outputs (last two timed steps = both batches): finite everywhere, every image the
+    # reference digest holds against it (rank 0: images 0..15; rank 1 with B = 8: none left -> finite only)
+    finite = all(bool(torch.isfinite(o[0]).all()) and bool(torch.isfinite(o[2]).all()) for _, o in outs)
+    parity = {"outputs_finite": finite, "parity_checked": False, "ok": finite}
+    dpath = digest.golden_path("demo_digest.npz")
+    if args.geometry == "demo" and os.path.exists(dpath):
+        dg = digest.load(dpath)
+        res = [digest.check_cascade(o[0], o[1], o[2], dg, ids[k]) for k, o in outs]
+        res = [r for r in res if r["checked_images"]]
+        if res:
+            parity.update({"parity_checked": True, "checked_images": sorted(set(i for r in res for i in r["checked_images"])),
+                           "reference": "tests/golden/demo_digest.npz: the reference's own output per image (B = 1 forwards)",
+                           "mask_iou": round(min(r["min_iou"] for r in res), 6),
+                           "max_abs_mask_err": max(r["max_abs_mask_err"] for r in res),
+                           "max_abs_class_logit_err": max(r["max_abs_class_logit_err"] for r in res),
+                           "pred_equal": all(r["pred_equal"] for r in res), "tolerance": digest.TOL,
+                           "ok": bool(finite and all(r["ok"] for r in res))})
     # split-K hand-offs a tail workgroup gave up on (the tile is NaN then, caught above too): 0 in a healthy run
     parity["gemm_handoff_errors"] = sum(e.ws.gemm_errors() for e in (cas, cas.encoder, cas.decoder, cas.clip))
     parity["ok"] = bool(parity["ok"] and parity["gemm_handoff_errors"] == 0)
-    if world > 1:
-        okt = torch.tensor([int(parity["ok"])], device=dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        parity["all_ranks_ok"] = bool(int(okt.item()))
+    parity["all_ranks_ok"] = all_ranks(parity["ok"])
+    rates = rank_rates(mine, B)
 
     # ---- roofline of the dominant kernel (instrumented repeat; not part of `value`)
     roofline = None
     if not args.no_roofline and rank == 0:
-        records, arecs = [], {"global": [], "window": []}
-        orig, orig_attn = hip.gemm, hip.attention
         nrep = max(1, min(args.steps, 2))
-
-        def timed_gemm(a, w, M, N, K, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(a, w, M, N, K, **kw)
-            e1.record()
-            records.append((2.0 * M * N * K * kw.get("batch", 1), e0, e1))
-
-        def timed_attn(qkv, o, Bn, S, heads, hd, **kw):
-            mode = kw.get("mode", 0)
-            if mode not in (1, 2):
-                return orig_attn(qkv, o, Bn, S, heads, hd, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig_attn(qkv, o, Bn, S, heads, hd, **kw)
-            e1.record()
-            if mode == 1:                                   # global: every query x every key
-                fl = 4.0 * S * S * hd * heads * Bn
-            else:                                           # 14x14 windows of the padded map (image_encoder.py:507-530)
-                w = kw["window"]
-                G = kw["grid"]
-                nw = -(-G // w)
-                fl = 4.0 * (w * w) ** 2 * hd * heads * Bn * nw * nw
-            arecs["global" if mode == 1 else "window"].append((fl, e0, e1))
-
-        hip.gemm, hip.attention = timed_gemm, timed_attn
         was_overlap = cas.overlap_clip
         cas.overlap_clip = False                            # per-kernel event times need the kernels one at a time
         try:
-            for _ in range(nrep):
-                step()
+            with Roofline(torch, hip, cas.prec.gemm) as rf:
+                step(1)                                     # leaves a stage 2 owed, so that both repeats below run the fused CLIP forward
+                rf.records.clear(); rf.arecs["global"].clear(); rf.arecs["window"].clear()
+                for i in range(nrep):
+                    step(i % 2)
+                torch.cuda.synchronize()
+            cas.flush()
             torch.cuda.synchronize()
         finally:
-            hip.gemm, hip.attention = orig, orig_attn
             cas.overlap_clip = was_overlap
-        traffic, tnote = None, None
-        for tname in ("r02_gemm_traffic.json",):   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-            tfile = os.path.join(REPO, "profiles", tname)
-            if args.geometry == "demo" and args.precision == "exact" and B == 8 and os.path.exists(tfile):
-                with open(tfile) as f:
-                    traffic = round(json.load(f)["traffic_bytes_per_launch"])
-                tnote = ("REPLAYED, not measured in this run: HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE "
-                         f"(x2 gfx950 correction) and WRITE_SIZE passes of this command (profiles/{tname})")
-                break
-        flops = sum(r[0] for r in records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in records)
-        achieved = flops / (ms * 1e-3) / 1e12
-        secondary = []
-        for name, kern in (("global", "attn_g64pair_kernel (ViT-H global attention, 64x64 map)"),
-                           ("window", "attn_win14_kernel (ViT-H 14x14 window attention)")):
-            rs = arecs[name]
-            if rs:
-                f_, m_ = sum(r[0] for r in rs), sum(r[1].elapsed_time(r[2]) for r in rs)
-                secondary.append({"kernel": kern, "bound": "mfma", "achieved": round(f_ / (m_ * 1e-3) / 1e12, 2),
-                                  "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(f_ / (m_ * 1e-3) / 1e12 / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-                                  "launches": len(rs), "avg_launch_us": round(1e3 * m_ / len(rs), 2),
-                                  "algorithmic_gflop_per_launch": round(f_ / len(rs) / 1e9, 3),
-                                  "note": "algorithmic FLOPs (4*S^2*hd per head, SURVEY.md §8d); exact mode issues 3 MFMAs per "
-                                          "product and pads hd 80 -> 96 in P.V, so the issued rate is 3-3.3x this"})
-        roofline = {"kernel": "gemm_nt_kernel<split=%d>" % cas.prec.gemm, "bound": "mfma",
-                    "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
-                    "launches": len(records), "avg_launch_us": round(1e3 * ms / len(records), 2),
-                    "algorithmic_gflop_per_launch": round(flops / len(records) / 1e9, 3),
-                    "gemm_share_of_step": round(ms * 1e-3 / nrep / (my_elapsed / args.steps), 3),
-                    "issued": round(achieved * cas.prec.gemm, 2),
-                    "issued_note": "MFMA flops issued: the exact mode forms every product from 3 f16 MFMAs (hi.hi + lo.hi + hi.lo)",
-                    "power_roofline": {"peak": MFMA_F16_POWER_ROOFLINE_TFLOPS, "unit": "TFLOP/s issued",
-                                       "frac_issued": round(achieved * cas.prec.gemm / MFMA_F16_POWER_ROOFLINE_TFLOPS, 4),
-                                       "note": "what an MFMA-only loop sustains at the 1400-W socket cap with random operands "
-                                               "(profiles/r02_power_roofline.log); the GEMM itself runs AT the cap: its energy per "
-                                               "launch = matrix pipe 51 % + L2->LDS DMA 26 % + idle 21 % (DESIGN.md section 6)"},
-                    "secondary": secondary}
+        roofline = rf.result(nrep, mine / args.steps,
+                             traffic_ok=(args.geometry == "demo" and args.precision == "exact" and B == 8))
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N = 1)
     cpu = None
@@ -394,9 +742,7 @@ def main():
         torch.set_num_threads(cores)
         osd = O.to_torch_sd(sd_np)
         n_warm, n_img = (1, 3) if args.geometry == "demo" else (1, 1)
-        cpu_in = [t[:n_warm + n_img].cpu() if t.shape[0] >= n_warm + n_img else None for t in (inp, ci, cm)]
-        if cpu_in[0] is None:                           # batch smaller than the sample: make the images
-            cpu_in = [torch.from_numpy(t) for t in synth.make_inputs(g, c, batch=n_warm + n_img)]
+        cpu_in = [torch.from_numpy(t) for t in synth.make_inputs(g, c, batch=n_warm + n_img)]
         with torch.no_grad():
             tfc = tf.cpu()
             times = []
@@ -420,38 +766,28 @@ def main():
                        "text_encoder_seconds, the encoder timed once on the same cores",
                "cpu_model": cpu_model(), "host_cores": host_cores}
 
-    if rank == 0:
-        line = {
-            "metric": "images/sec at 1024x1024 (SAM-ViT-H + CLIP ViT-L/14), full cascade",
-            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": {"exact": "f32-grade (3x f16 split MFMA, f32 accumulate)", "mixed": "f32-grade GEMM/QK, f16 PV",
-                      "fast": "f16 operands, f32 accumulate"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": "full cascade: SAM-Adapter ViT-H 1024^2 encoder + edge mask decoder + "
-                                   "Alpha-CLIP ViT-L/14@336 x2 passes, 61 OVCamo prompts (BASELINE configs[2])"
-                       if args.geometry == "demo" else "tiny geometry (debug)",
-                       "images_per_gpu_per_step": B, "global_batch": B * world, "precision": args.precision,
-                       "parallelism": f"dp{world} (images sharded, text bank all-gathered)",
-                       "clip_pass1_overlap": bool(cas.overlap_clip), "stage2_pipelined_under_next_batch": bool(cas.overlap_clip),
-                       "text_bank_seconds_once": round(text_bank_s, 3), "setup_seconds": round(setup_s, 1)},
-            "step_ms": {"median": round(percentile(step_ms, 0.5), 3), "p10": round(percentile(step_ms, 0.1), 3),
-                        "p90": round(percentile(step_ms, 0.9), 3), "n": len(step_ms),
-                        "note": "per-step HIP-event durations of the timed steps on rank 0"},
-            "images_per_s_per_gpu": round(value / world, 3),
-            "achieved_tflops_algorithmic": round(value * WORK_TFLOP_PER_IMAGE, 1) if args.geometry == "demo" else None,
-            "parity": parity, "bank_check": bank_check, "power": power,
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
-    failed = not parity.get("all_ranks_ok", parity["ok"]) or (bank_check is not None and
-                                                             not bank_check["bit_identical_to_single_rank_bank_on_every_rank"])
-    if world > 1:
-        dist.barrier()                                   # rank 0 ran the instrumented roofline repeat meanwhile
-        dist.destroy_process_group()
-    if failed:
-        sys.exit(3)
+    line = {
+        "metric": "images/sec at 1024x1024 (SAM-ViT-H + CLIP ViT-L/14), full cascade",
+        "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
+        "config": {"workload": "full cascade: SAM-Adapter ViT-H 1024^2 encoder + edge mask decoder + "
+                               "Alpha-CLIP ViT-L/14@336 x2 passes, 61 OVCamo prompts (BASELINE configs[2])"
+                   if args.geometry == "demo" else "tiny geometry (debug)",
+                   "images_per_gpu_per_step": B, "global_batch": B * world, "precision": args.precision,
+                   "parallelism": f"dp{world} (images sharded, text bank all-gathered)",
+                   "distinct_batches_alternating": 2,
+                   "clip_pass1_overlap": bool(cas.overlap_clip), "stage2_pipelined_under_next_batch": bool(cas.overlap_clip),
+                   "stage2_fused_with_next_pass1": bool(cas.fuse_clip),
+                   "text_bank_seconds_once": round(text_bank_s, 3), "setup_seconds": round(setup_s, 1)},
+        "step_ms": step_block(step_ms),
+        "images_per_s_per_gpu": round(value / world, 3), "images_per_s_per_rank": rates,
+        "achieved_tflops_algorithmic": round(value * WORK_TFLOP_PER_IMAGE, 1) if args.geometry == "demo" else None,
+        "parity": parity, "bank_check": bank_check, "power": power,
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    ok = parity["all_ranks_ok"] and (bank_check is None or bank_check["bit_identical_to_single_rank_bank_on_every_rank"])
+    finish(line, ok)
 
 
 if __name__ == "__main__":

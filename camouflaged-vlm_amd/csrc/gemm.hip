@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int BK_MIN = 32;
+constexpr float LN_FOLD_MAX_RATIO = 128.f;      // |row mean| / row sigma the LayerNorm-folded epilogue accepts (include/cvlm.h)
 
 // chunk permutation g(q), q = (row >> 2) & 3 (derived for the ds_read_b128 lane groups)
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
@@ -42,7 +43,7 @@ struct GemmParams {
     int tail_rem, tail_split;
     int total_blocks;  // PERSIST: workgroup b walks ids b, b + gridDim.x, ... < total_blocks
     float* ws;
-    unsigned* flags;   // [tail_rem][4] arrival words (1 when ready; the consumer puts 0 back), then one error word at [4 * 128]
+    unsigned* flags;   // [tail_rem][4] arrival words (1 when ready; the consumer puts 0 back), then error words at [4 * 128] (abandoned hand-offs), [4 * 128 + 1] (LayerNorm-fold rows out of range)
 #ifdef CVLM_PROBES
     unsigned long long* trace;   // DBG == 4 only: 8 x u64 per workgroup (timeline probe, tools/trace_gemm.py)
 #endif
@@ -693,7 +694,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         for (int pc = 1; pc < P; pc += 2) a1 += part(pc);
                         m2 = a0 + a1;
                     }
-                    const float rs = __builtin_amdgcn_rsqf(fmaxf(m2 * ln_inv_d, 0.f) + g.ln_eps);
+                    float rs = __builtin_amdgcn_rsqf(fmaxf(m2 * ln_inv_d, 0.f) + g.ln_eps);
+                    // Guaranteed range of the fold: alpha * acc - mu * colsum cancels |mu| / sigma of the operand format's 22 bits
+                    // (measured: error 4e-6 * |mu| / sigma per output).  A row beyond LN_FOLD_MAX_RATIO does not get a plausible
+                    // wrong value: its outputs become NaN and the workspace counts it (include/cvlm.h).
+                    if (fabsf(mu) * rs > LN_FOLD_MAX_RATIO) {
+                        rs = __builtin_nanf("");
+                        if (h == 0 && p.flags && e_bn == 0 && e_bm + r < g.M) atomicAdd(&p.flags[4 * 128 + 1], 1u);
+                    }
                     if (h == 0) sbuf[r] = make_float2(rs, mu * rs);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1000,7 +1008,7 @@ static int tail_parts(int rem, int K) {
 // ---- tail-split workspace (caller-owned, include/cvlm.h): [4 KiB hand-off words][128 tiles x 3 parts of 256 x 256 f32]
 constexpr size_t TAIL_FLAG_BYTES = 4096;
 constexpr size_t TAIL_WS_BYTES = (size_t)128 * 3 * 256 * 256 * sizeof(float);
-static_assert((4 * 128 + 1) * sizeof(unsigned) <= TAIL_FLAG_BYTES, "hand-off words fit the flag page");
+static_assert((4 * 128 + 2) * sizeof(unsigned) <= TAIL_FLAG_BYTES, "hand-off words fit the flag page");
 
 extern "C" int64_t cvlm_gemm_workspace_bytes(void) { return (int64_t)(TAIL_FLAG_BYTES + TAIL_WS_BYTES); }
 
@@ -1059,6 +1067,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr;
     p.total_blocks = 0;
     const bool have_ws = g.workspace && g.workspace_bytes >= cvlm_gemm_workspace_bytes();
+    if (have_ws) p.flags = (unsigned*)g.workspace;                   // word 513: rows refused by the LayerNorm fold
     hipStream_t s = (hipStream_t)stream;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
     int variant = variant_env;

@@ -799,13 +799,21 @@ class ClipModel(_Base):
         hip.gather_rows_h2(xh, inv, Bn, L, Wd, None, 0, cls)
         return cls
 
-    def image_features(self, image: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
-        """alpha_clip_rw/model.py:528-563 -> f32 [B][embed_dim] (un-normalised)."""
+    def image_features(self, image, alpha) -> torch.Tensor:
+        """alpha_clip_rw/model.py:528-563 -> f32 [B][embed_dim] (un-normalised).  `image` / `alpha` may be LISTS of tensors:
+        the groups are stacked along the batch axis inside the patch matrix (no copy of the inputs) and run as one forward
+        -- the fused stage-2 + next-pass-1 step of Cascade.cascade(pipelined=True)."""
         c, ws = self.c, self.ws
-        B = image.shape[0]
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        alphas = list(alpha) if isinstance(alpha, (list, tuple)) else [alpha]
+        B = sum(int(t.shape[0]) for t in images)
         P, Wd, L = c.grid * c.grid, c.vision_width, c.n_tokens
         pt = ws.h2("cpatch", B * P, self.conv.K)
-        hip.patchify(image, alpha, c.patch_size, pt, self.conv.K)
+        r0 = 0
+        for im, al in zip(images, alphas):
+            b = int(im.shape[0])
+            hip.patchify(im, al, c.patch_size, H2(pt.t[:, r0 * P:(r0 + b) * P]), self.conv.K)
+            r0 += b
         pe = ws.f32("cpe", B * P, Wd)
         self.gemm(pt, self.conv, B * P, out_f32=pe)
         x = ws.f32("cx", B, L, Wd)
@@ -854,9 +862,9 @@ class ClipModel(_Base):
 
     def forward(self, image: torch.Tensor, alpha: torch.Tensor, split: str = "test"):
         """CustomCLIP.forward test branch (mapleAlphaCLIP.py:281-294)."""
-        B = image.shape[0]
         txt = self.txt[split]
-        feat = self.image_features(image, alpha)
+        feat = self.image_features(image, alpha)              # lists of tensors: one forward over the stacked groups
+        B = feat.shape[0]
         n, D = txt.shape
         img_n = torch.empty(B, D, device=self.device)
         logits = torch.empty(B, n, device=self.device)
@@ -889,6 +897,12 @@ class Cascade(_Base):
         # (bench.py --no-overlap) serialises it for profiling: co-running kernels stretch each other's durations,
         # which blurs per-kernel evidence.
         self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "1") == "1"
+        # pipelined loop: stage 2 of batch i and CLIP pass 1 of batch i+1 -- same weights, back to back on the side stream -- run
+        # as ONE vision-tower forward over both batches (M = 9296 at B = 8: 36 row tiles instead of twice 18.2; out_proj 148
+        # tiles on 256 CUs instead of twice 76).  CVLM_FUSE_CLIP=0 keeps the two forwards apart.
+        self.fuse_clip = os.environ.get("CVLM_FUSE_CLIP", "1") == "1"
+        self._pending = None                                         # (masks, clip_image, pred, logits) of the batch whose stage 2 is still owed
+        self._pending_stream = None
         self._side = None
         self._done = [None, None]                                    # side-stream completion events of the last two batches
         self._parity = 0
@@ -909,6 +923,7 @@ class Cascade(_Base):
         return sparse
 
     def infer_test(self, inp, clip_image, clip_mask, taps: Optional[dict] = None) -> torch.Tensor:
+        self.flush()
         g = self.g
         B = inp.shape[0]
         # CLIP pass 1 only needs (clip_image, clip_mask): it runs on a side stream underneath the SAM encoder so
@@ -948,6 +963,9 @@ class Cascade(_Base):
         pipelined=True: it does not -- the caller's next batch starts its encoder underneath this batch's decoder and
         stage 2 (a serving loop: results are complete after `torch.cuda.synchronize()` or once the side stream has been
         waited for; the next `cascade()` orders itself behind the previous one, at most one batch is in flight there)."""
+        if pipelined and self.fuse_clip:
+            return self._cascade_fused(inp, clip_image, clip_mask)
+        self.flush()
         if not self.overlap_clip:
             masks = self.infer_test(inp, clip_image, clip_mask)
             _, _, pred, logits = self.stage2(masks, clip_image)
@@ -984,3 +1002,70 @@ class Cascade(_Base):
         if not pipelined:
             main.wait_stream(side)
         return masks, pred, logits
+
+    def _cascade_fused(self, inp, clip_image, clip_mask):
+        """pipelined=True with the two CLIP forwards of a step fused: this call launches, on the side stream, ONE vision-tower
+        forward over [stage 2 of the PREVIOUS batch | pass 1 of this batch], then this batch's decoder behind its encoder; the
+        stage 2 of this batch is owed until the next call -- or `flush()`, which a caller that stops feeding batches must
+        issue (bench.py does, inside the timed region).  The returned `pred` / `logits` tensors are filled by that later
+        launch; `masks` by this one.  cocotrainers/mapleAlphaCLIP.py:281-294 twice, demo.py:117-122."""
+        g, B = self.g, inp.shape[0]
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        side = self._side if self.overlap_clip else main             # overlap_clip = False: same launches, one stream (profiling)
+        self._pending_stream = side
+        if self._done[self._parity] is not None:                     # the batch before the previous one has left the side stream
+            main.wait_event(self._done[self._parity])
+        side.wait_stream(main)
+        prev = self._pending
+        with torch.cuda.stream(side):
+            if prev is None:
+                img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
+            else:
+                p_masks, p_image, p_pred, p_logits = prev
+                Bp, R = p_masks.shape[0], self.c.image_resolution
+                alpha = self.ws.f32("alpha2", Bp, 1, R, R)
+                hip.bilinear(p_masks, Bp, g.inp_size, g.inp_size, alpha, R, R, sigmoid_in=True)
+                img_n, sel, pred_all, logits_all = self.clip.forward([p_image, clip_image], [alpha, clip_mask])
+                p_pred.copy_(pred_all[:Bp])                          # results of the previous batch land in the tensors it returned
+                p_logits.copy_(logits_all[:Bp])
+                img_f, txt_f = img_n[Bp:], sel[Bp:]
+        feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+        enc_done = torch.cuda.Event()
+        enc_done.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(enc_done)
+            sparse = self.sparse_prompts(img_f, txt_f, B)
+            low = self.decoder.forward(feats, sparse, self.no_mask, self.gauss, B, None)
+            masks = torch.empty(B, 1, g.inp_size, g.inp_size, device=self.device)
+            hip.bilinear(low, B, 4 * g.grid, 4 * g.grid, masks, g.inp_size, g.inp_size)
+            n_cls = self.clip.txt["test"].shape[0]
+            pred = torch.empty(B, dtype=torch.int64, device=self.device)
+            logits = torch.empty(B, n_cls, device=self.device)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._done[self._parity] = done
+        self._parity ^= 1
+        self._pending = (masks, clip_image, pred, logits)
+        for t in (inp, clip_image, clip_mask):
+            t.record_stream(side)
+        for t in (masks, pred, logits):
+            t.record_stream(main)
+        return masks, pred, logits
+
+    def flush(self) -> None:
+        """Launch the stage 2 that `cascade(pipelined=True)` still owes for its last batch (no-op otherwise); results are
+        complete once the side stream has been waited for / after `torch.cuda.synchronize()`."""
+        prev, self._pending = self._pending, None
+        if prev is None:
+            return
+        p_masks, p_image, p_pred, p_logits = prev
+        side = self._pending_stream
+        with torch.cuda.stream(side):
+            _, _, pred, logits = self.stage2(p_masks, p_image)
+            p_pred.copy_(pred)
+            p_logits.copy_(logits)
+            done = torch.cuda.Event()
+            done.record(side)
+        self._done[self._parity ^ 1] = done                          # the slot of the batch just completed

@@ -115,8 +115,10 @@ def new_gemm_workspace(device) -> torch.Tensor:
 
 
 def gemm_workspace_errors(ws: torch.Tensor) -> int:
-    """Abandoned split-K hand-offs recorded in a workspace (word 512; synchronises).  0 in a healthy run."""
-    return int(ws[2048:2052].view(torch.int32).item())
+    """Abandoned split-K hand-offs (word 512) + rows a LayerNorm-folded launch refused (word 513) recorded in a workspace
+    (synchronises).  Either kind has already turned the affected outputs into NaN.  0 in a healthy run."""
+    words = ws[2048:2056].view(torch.int32).tolist()
+    return int(words[0]) + int(words[1])
 
 
 class H2:

@@ -54,7 +54,8 @@ const char* cvlm_target_arch(void);
  * workspace (fixed summation order); without it every tile is computed whole (same result up to fp32 summation
  * order, slower for 2.5-round shapes).  The first 4 KiB of the workspace are hand-off words: zero them ONCE after
  * allocation (hipMemset); kernels leave them zero.  Word 512 counts abandoned hand-offs (a partner workgroup that
- * never arrived; the affected tile is written as NaN): 0 in a healthy run.
+ * never arrived; the affected tile is written as NaN), word 513 rows a LayerNorm-folded launch refused (below): 0 in a
+ * healthy run.
  */
 typedef struct cvlm_gemm_args {
     const void* a_hi; const void* a_lo; int64_t lda; int64_t stride_a;
@@ -80,6 +81,9 @@ typedef struct cvlm_gemm_args {
      * planes M rows apart (float [P][M][2]; the layout `row_stats` of the producing launch and cvlm_row_stats_split write).
      * The consumer merges the pieces of a row in a fixed order (even pieces, odd pieces, then the two), so the result is
      * bit-reproducible, and as centred moments (no s2 / D - mu^2 cancellation on rows whose mean dwarfs their spread).
+     * Guaranteed range: the fold subtracts mu * colsum from a contraction of the UN-centred row, which costs |mu| / sigma of the
+     * h2 format's 22 bits (measured 4e-6 * |mu| / sigma abs per output); rows with |mu| / sigma > 128 are refused: their
+     * outputs are NaN and, with a workspace, word 513 of its first page counts them (never a finite wrong value).
      * h2 output only, act in {NONE, GELU, QUICKGELU}, N % 8 == 0. */
     const float* ln_stats; const float* ln_colsum; float ln_eps; int32_t ln_D;
     /* ABI 3 -- the producer side: residual given as h2 planes (value = (hi + lo) * res_scale, leading dimension ldrh) and
