@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
                                                             const half_t* __restrict__ vt_lo) {
     // L = side of the token map (64: 1024^2 images, 96: 1536^2).  A key row is TPR = L / 32 tiles; the 96 map needs a
     // 99 KB Th table, so its V ring has two slots instead of three (fetched one phase later, drained, see tile_phases)
-    constexpr int HD = 80, KS = 5, ND = 3, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, TPR = L / KT;
+    constexpr int HD = 80, KS = 5, NDB = 5, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, TPR = L / KT;
     constexpr int NSV = (L == 64) ? 3 : 2;
     static_assert(L % KT == 0 && S % 256 == 0 && NTILE % TPR == 0, "map side");
     constexpr int VROWS = 96, VROW_B = KT * 2;                       // V^T image: 96 rows (80 dims + 16 filler) x 32 keys
@@ -187,14 +187,16 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 
     // ---- state
     float m_run = -INFINITY, l_run = 0.f;
-    floatx16 o[ND], s;
+    floatx16 s;
+    floatx4 o[NDB][2];                                               // O^T tiles (16x16x32 P.V, see attn_g64pair_kernel): [16-dim block][query block]
 #pragma unroll
-    for (int n = 0; n < ND; ++n)
+    for (int n = 0; n < NDB; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-    half8 ph[2] = {}, pl[2] = {};
-    // byte offset of this lane's key chunk (keys 16 k2 + 8 half ..) inside its V^T row; rows 32 n + qc share (row >> 2) & 3
-    const int v_pos[2] = {((0 + half) ^ ((qc >> 2) & 3)) * 16, ((2 + half) ^ ((qc >> 2) & 3)) * 16};
+        for (int qb = 0; qb < 2; ++qb) o[n][qb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 xh[2] = {}, xl[2] = {};                                    // P^T as B operands of the 16x16x32 shape, per query block
+    // V^T fragment of this lane: row (lane & 15) of a 16-row block, key group lane >> 4; position swizzled like the DMA image
+    const int v_lane_off = (lane & 15) * VROW_B + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16);
     const int k_lane_off = qc * KP + 8 * half;
 
     auto QK = [&](int slot) {                                        // S^T = K_tile . Q^T  (3 MFMAs per k-step)
@@ -210,30 +212,22 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
         }
     };
-    // Y(t): O^T += V(t)^T . P^T (six fragment groups), then S^T = K(t+1) . Q^T (five k-steps) as ONE stream of
-    // eleven stages; the LDS fragments of stage i + 2 are requested before the three MFMAs of stage i are issued.
-    // The partner wave on this SIMD is in its VALU phase, so nothing else would cover this wave's LDS latency.
+    // Y(t): O^T += V(t)^T . P^T (five 16-dim blocks, six 16x16x32 MFMAs each), then S^T = K(t+1) . Q^T (five k-steps, three
+    // 32x32x16 MFMAs each) as ONE stream of ten stages; the LDS fragments of stage i + PD are requested before the MFMAs of
+    // stage i.  The partner wave on this SIMD is in its VALU phase, so nothing else would cover this wave's LDS latency.
     auto Y = [&](int vslot, int kslot) {
-        const unsigned char* vbase = Vring + vslot * VSLOT_B + qc * VROW_B;      // row = 32 n + qc of the V^T image
+        const unsigned char* vbase = Vring + vslot * VSLOT_B + v_lane_off;
         const half_t* kr = (const half_t*)(Kring + kslot * KSLOT_B) + k_lane_off;
-        constexpr int PD = CVLM_G64_PD, RS = PD + 1;                 // fragments requested PD stages ahead, ring of PD + 1
+        constexpr int PD = CVLM_G64_PD, RS = PD + 1, NST = NDB + 5;    // fragments requested PD stages ahead, ring of PD + 1
         half8 fa[RS], fb[RS];                                        // (hi, lo) fragment pair per stage
         auto load = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
-#ifdef CVLM_G64_NOLDS                                                // probe: 1 = no fragment reads, 2 = no V reads, 3 = no K reads
-            if constexpr (CVLM_G64_NOLDS == 1 || (CVLM_G64_NOLDS == 2 && I < 6) || (CVLM_G64_NOLDS == 3 && I >= 6)) {
-                fa[I % RS] = qh[I % 5]; fb[I % RS] = ql[I % 5];
-                asm volatile("" : "+v"(fa[I % RS]), "+v"(fb[I % RS]));
-                return;
-            }
-#endif
-            if constexpr (I < 6) {
-                constexpr int k2 = I / 3, n = I % 3;
-                const unsigned char* vr = vbase + (32 * n) * VROW_B + v_pos[k2];
+            if constexpr (I < NDB) {
+                const unsigned char* vr = vbase + (16 * I) * VROW_B;
                 fa[I % RS] = *(const half8*)vr;
                 fb[I % RS] = *(const half8*)(vr + VPL_B);
             } else {
-                constexpr int ks = I - 6;
+                constexpr int ks = I - NDB;
                 fa[I % RS] = *(const half8*)(kr + 16 * ks);
                 fb[I % RS] = *(const half8*)(kr + KPL + 16 * ks);
             }
@@ -241,13 +235,16 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
         auto compute = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
             const half8 a = fa[I % RS], bq = fb[I % RS];
-            if constexpr (I < 6) {
-                constexpr int k2 = I / 3, n = I % 3;
-                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ph[k2], o[n], 0, 0, 0);
-                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, ph[k2], o[n], 0, 0, 0);
-                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pl[k2], o[n], 0, 0, 0);
+            if constexpr (I < NDB) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const half8 bh = __builtin_bit_cast(half8, xh[qb]), bl = __builtin_bit_cast(half8, xl[qb]);
+                    o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[I][qb], 0, 0, 0);
+                    o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[I][qb], 0, 0, 0);
+                    o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[I][qb], 0, 0, 0);
+                }
             } else {
-                constexpr int ks = I - 6;
+                constexpr int ks = I - NDB;
                 if constexpr (ks == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -262,15 +259,8 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
         if constexpr (PD >= 3) load(std::integral_constant<int, 2>{});
         auto stage = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
-            if constexpr (I + PD <= 10) load(std::integral_constant<int, I + PD>{});
+            if constexpr (I + PD < NST) load(std::integral_constant<int, I + PD>{});
             compute(ic);
-            // issue order inside the stage: MFMA, two LDS reads, MFMA, two LDS reads, MFMA -- a burst of four reads
-            // in front of the MFMAs stalled their issue by ~40 cycles per stage (LDS queue), two per gap are free
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         stage(std::integral_constant<int, 0>{}); stage(std::integral_constant<int, 1>{});
@@ -278,7 +268,6 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
         stage(std::integral_constant<int, 4>{}); stage(std::integral_constant<int, 5>{});
         stage(std::integral_constant<int, 6>{}); stage(std::integral_constant<int, 7>{});
         stage(std::integral_constant<int, 8>{}); stage(std::integral_constant<int, 9>{});
-        stage(std::integral_constant<int, 10>{});
     };
     // X(t): online softmax of S -> P (hi, lo fragments).  Q carries `scale`, so S is already in score units; the VALU
     // issue port is what bounds this phase (the partner's MFMAs take 8 of every 32 issue cycles), hence: packed fp32
@@ -286,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
     // split as cvt_pkrtz + (e - hi) + cvt_pkrtz (hi truncated instead of rounded: lo absorbs the difference exactly).
     auto X = [&](const f32x2 (&tw)[8], float th) {
 #ifdef CVLM_G64_NOX
-        asm volatile("" : "+v"(ph[0]), "+v"(ph[1]), "+v"(pl[0]), "+v"(pl[1]));   // probe: no VALU phase
+        asm volatile("" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xl[0]), "+v"(xl[1]));   // probe: no VALU phase
         return;
 #endif
         f32x2 z[8];
@@ -308,22 +297,25 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
         }
         l_run = l_run * alpha + (acc.x + acc.y);
         if (!__all(m_new == m_run)) {
+            const auto ax = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, alpha), __builtin_bit_cast(unsigned, alpha), false, false);
+            const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
 #pragma unroll
-            for (int n = 0; n < ND; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
         }
         m_run = m_new;
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const f32x2 e = z[4 * k2 + p];
-                const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x, e.y));
-                const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x - (float)h[0], e.y - (float)h[1]));
-                ph[k2][2 * p] = h[0]; ph[k2][2 * p + 1] = h[1];
-                pl[k2][2 * p] = l[0]; pl[k2][2 * p + 1] = l[1];
-            }
+        for (int p = 0; p < 4; ++p) {                                // first / last eight values -> the two B operands (see attn_g64pair_kernel)
+            const f32x2 v0 = z[p], v1 = z[4 + p];
+            const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
+            const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
+            const half2v f0 = __builtin_bit_cast(half2v, h0), f1 = __builtin_bit_cast(half2v, h1);
+            const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)f0[0], v0.y - (float)f0[1]));
+            const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)f1[0], v1.y - (float)f1[1]));
+            const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
+            const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+            xh[0][p] = (unsigned)rh[0]; xh[1][p] = (unsigned)rh[1];
+            xl[0][p] = (unsigned)rl[0]; xl[1][p] = (unsigned)rl[1];
+        }
     };
 
     // ---- every wave runs the same sequence  QK(0) | X(0) Y(0) | X(1) Y(1) | ...  with Y(t) = PV(t), QK(t+1);
@@ -347,14 +339,14 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
         unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (trace) c0 = wall_clock64();
         X(twr[PZ], Tq[t / TPR]);
-        if (trace) { asm volatile("" ::"v"(ph[0]), "v"(pl[1])); c1 = wall_clock64(); }
+        if (trace) { asm volatile("" ::"v"(xh[0]), "v"(xl[1])); c1 = wall_clock64(); }
         if (!grpB) { if (t + 5 >= NTILE) wait_vm<0>(); else wait_vm<DPW>(); }
         phase_barrier();
         if (trace) c2 = wall_clock64();
         if (!grpB) { if (t + 3 < NTILE) issue_next(s0); }
         else if (NSV == 3) { if (t + 2 < NTILE) issue_next(s2); }
         Y(NSV == 3 ? s0 : (t & 1), s1);                             // the last S (tile NTILE) is computed and dropped
-        if (trace) { asm volatile("" ::"v"(s[0]), "v"(o[2][0])); c3 = wall_clock64(); }
+        if (trace) { asm volatile("" ::"v"(s[0]), "v"(o[4][1][0])); c3 = wall_clock64(); }
         if (grpB) { if (NSV == 2 || t + 5 >= NTILE) wait_vm<0>(); else wait_vm<DPW>(); }
         phase_barrier();
         if (trace) { const unsigned long long c4 = wall_clock64(); tr_x += c1 - c0; tr_xb += c2 - c1; tr_y += c3 - c2; tr_yb += c4 - c3; }
@@ -370,22 +362,23 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 
     const float l_tot = half_swap_sum(l_run);
     const float inv = 1.0f / l_tot;
-    const int64_t orow = ((int64_t)b * S + qslot) * D + head * HD;
-    half_t* oh = (half_t*)g.out_hi + orow;
-    half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
+    const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
+    const float invq[2] = {__builtin_bit_cast(float, (unsigned)ix[0]), __builtin_bit_cast(float, (unsigned)ix[1])};
 #pragma unroll
-    for (int n = 0; n < ND; ++n)
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qs2 = blockIdx.x * 256 + wave * 32 + 16 * qb + (lane & 15);
+        const int64_t orow = ((int64_t)b * S + qs2) * D + head * HD + 4 * (lane >> 4);
+        half_t* oh = (half_t*)g.out_hi + orow;
+        half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int d = 32 * n + 8 * rg + 4 * half;
-            if (d < HD) {
-                half_t h[4], l4[4];
+        for (int n = 0; n < NDB; ++n) {
+            half_t h[4], l4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) split_h2(o[n][4 * rg + j] * inv, h[j], l4[j]);
-                *(half4*)(oh + d) = half4{h[0], h[1], h[2], h[3]};
-                if (ol) *(half4*)(ol + d) = half4{l4[0], l4[1], l4[2], l4[3]};
-            }
+            for (int j = 0; j < 4; ++j) split_h2(o[n][qb][j] * invq[qb], h[j], l4[j]);
+            *(half4*)(oh + 16 * n) = half4{h[0], h[1], h[2], h[3]};
+            if (ol) *(half4*)(ol + 16 * n) = half4{l4[0], l4[1], l4[2], l4[3]};
         }
+    }
     if (trace && lane == 0) {
         unsigned long long* o8 = trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
         o8[0] = tr_pro; o8[1] = tr_x; o8[2] = tr_xb; o8[3] = tr_y; o8[4] = tr_yb; o8[5] = wall_clock64() - tr_start;
@@ -401,9 +394,17 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 // 66 MFMAs back to back (P.V of both tiles, then the scores of the next two).  Half the phases and barriers per key.
 // Rings: four K and four V slots (two pairs each); a carrier refills the pair that was read in the previous round, the
 // batch has two phases to land and is retired with vmcnt(0) (no younger batch is in flight at that point).
+//
+// Round 3: P.V on 16x16x32 MFMAs.  The scores keep the 32x32x16 shape (its K = 16 steps cover head_dim 80 exactly; the
+// 16-wide shape would pad the contraction to 96), but O^T = V^T.P^T now runs as 16 x 16 output tiles: head_dim 80 = 5 tiles,
+// no padding to 96 (60 MFMAs of 16 cycles per 64 keys instead of 36 of 32: -17 % of the P.V matrix cycles), on the shape
+// whose bare loop delivers 1.12-1.15x the flops per joule (MI355X_MICROARCH.md) -- the kernel runs at the power cap.
+// The P values leave the softmax in the 32x32 accumulator layout (lane = (query, half), 16 keys); one v_permlane16_swap per
+// register pair turns them into the two B operands of the 16-wide shape (queries 0-15 / 16-31 of the wave, four key groups of
+// eight), V^T is stored in the matching key order by transpose_v_kernel.
 __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
                                                               const half_t* __restrict__ vt_lo) {
-    constexpr int L = 64, HD = 80, KS = 5, ND = 3, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, NPAIR = NTILE / 2;
+    constexpr int L = 64, HD = 80, KS = 5, NDB = 5, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, NPAIR = NTILE / 2;
     constexpr int VROWS = 96, VROW_B = KT * 2;
     constexpr int KPL_B = KT * KP * 2, VPL_B = VROWS * VROW_B;
     constexpr int KSLOT_B = 2 * KPL_B, VSLOT_B = 2 * VPL_B, NSLOT = 4;
@@ -535,13 +536,16 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
 
     // ---- state
     float m_run = -INFINITY, l_run = 0.f;
-    floatx16 o[ND], s[2];
+    floatx16 s[2];
+    floatx4 o[NDB][2];                                               // O^T tiles: [16-dim block][query block]: dims 16 db + 4 (lane >> 4) + j, query 16 qb + (lane & 15)
 #pragma unroll
-    for (int n = 0; n < ND; ++n)
+    for (int n = 0; n < NDB; ++n)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
-    half8 ph[2][2] = {}, pl[2][2] = {};                              // [tile of the pair][16-key step]
-    const int v_pos[2] = {((0 + half) ^ ((qc >> 2) & 3)) * 16, ((2 + half) ^ ((qc >> 2) & 3)) * 16};
+        for (int qb = 0; qb < 2; ++qb) o[n][qb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 xh[2][2] = {}, xl[2][2] = {};                              // P^T as B operands of the 16x16x32 shape: [tile of the pair][query block]
+    // V^T fragment of this lane: row (lane & 15) of a 16-row block, key group lane >> 4; position swizzled like the DMA image
+    const int v_lane_off = (lane & 15) * VROW_B + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16);
     const int k_lane_off = qc * KP + 8 * half;
 
     auto QK2 = [&](int kslot0) {                                     // scores of the pair in slots kslot0, kslot0 + 1
@@ -560,29 +564,28 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
             }
         }
     };
-    // Y(q): O^T += V^T.P^T for both tiles of pair q (12 fragment groups), then the scores of pair q + 1 (10 k-steps), as
-    // ONE stream of 22 stages; the LDS fragments of stage i + PD are requested before the three MFMAs of stage i.
+    // Y(q): O^T += V^T.P^T for both tiles of pair q (10 fragment groups: tile x 16-dim block, six 16x16x32 MFMAs each), then the
+    // scores of pair q + 1 (10 k-steps, three 32x32x16 MFMAs each), as ONE stream of 20 stages of 96 matrix cycles; the LDS
+    // fragments of stage i + PD are requested before the MFMAs of stage i.
     auto Y = [&](int vslot0, int kslot0) {
         // Fragment reads are inline asm with immediate offsets and COUNTED waits: left to hipcc, the stream got an
         // `s_waitcnt lgkmcnt(0)` every third stage, i.e. the full LDS latency (reads of three stages ahead included) was
-        // exposed seven times per phase: 1.9 us for 66 MFMAs that take 1.15 us.  LDS returns in order, so "all but the
-        // 2 * PD youngest reads" is exactly "stage I's two fragments have arrived".
-        const unsigned vb = (unsigned)(size_t)(LDS_AS const unsigned char*)(Vring + vslot0 * VSLOT_B + qc * VROW_B);
-        unsigned va[2] = {vb + (unsigned)v_pos[0], vb + (unsigned)v_pos[1]};
+        // exposed seven times per phase.  LDS returns in order, so "all but the 2 * PD youngest reads" is exactly
+        // "stage I's two fragments have arrived".
+        const unsigned va = (unsigned)(size_t)(LDS_AS const unsigned char*)(Vring + vslot0 * VSLOT_B) + (unsigned)v_lane_off;
         unsigned ka = (unsigned)(size_t)(LDS_AS const unsigned char*)(Kring + kslot0 * KSLOT_B) + 2u * (unsigned)k_lane_off;
-        constexpr int PD = CVLM_G64_PD, RS = PD + 1, NST = 22;
+        constexpr int PD = CVLM_G64_PD, RS = PD + 1, NPV = 2 * NDB, NST = NPV + 10;
         half8 fa[RS], fb[RS];
         auto load = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
-            const unsigned a_v0 = va[0], a_v1 = va[1], a_k = ka;     // named outside the `if constexpr` so that the lambda captures them
-            if constexpr (I < 12) {
-                constexpr int e = I / 6, k2 = (I % 6) / 3, n = I % 3;
-                constexpr int off = e * VSLOT_B + (32 * n) * VROW_B;
-                const unsigned a_v = k2 ? a_v1 : a_v0;
+            const unsigned a_v = va, a_k = ka;                        // named outside the `if constexpr` so that the lambda captures them
+            if constexpr (I < NPV) {
+                constexpr int e = I / NDB, db = I % NDB;
+                constexpr int off = e * VSLOT_B + (16 * db) * VROW_B;
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[I % RS]) : "v"(a_v), "n"(off));
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I % RS]) : "v"(a_v), "n"(off + VPL_B));
             } else {
-                constexpr int e = (I - 12) / 5, ks = (I - 12) % 5;
+                constexpr int e = (I - NPV) / 5, ks = (I - NPV) % 5;
                 constexpr int off = e * KSLOT_B + 32 * ks;
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[I % RS]) : "v"(a_k), "n"(off));
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I % RS]) : "v"(a_k), "n"(off + KPL_B));
@@ -591,13 +594,17 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
         auto compute = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
             const half8 a = fa[I % RS], bq = fb[I % RS];
-            if constexpr (I < 12) {
-                constexpr int e = I / 6, k2 = (I % 6) / 3, n = I % 3;
-                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ph[e][k2], o[n], 0, 0, 0);
-                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, ph[e][k2], o[n], 0, 0, 0);
-                o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pl[e][k2], o[n], 0, 0, 0);
+            if constexpr (I < NPV) {
+                constexpr int e = I / NDB, db = I % NDB;
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const half8 bh = __builtin_bit_cast(half8, xh[e][qb]), bl = __builtin_bit_cast(half8, xl[e][qb]);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[db][qb], 0, 0, 0);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[db][qb], 0, 0, 0);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[db][qb], 0, 0, 0);
+                }
             } else {
-                constexpr int e = (I - 12) / 5, ks = (I - 12) % 5;
+                constexpr int e = (I - NPV) / 5, ks = (I - NPV) % 5;
                 if constexpr (ks == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[e][r] = 0.f;
@@ -619,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
             __builtin_amdgcn_sched_barrier(0);
 #ifdef CVLM_G64_NOMFMA
             asm volatile("" ::"v"(fa[I % RS]), "v"(fb[I % RS]));                  // probe: fragment reads only
-            if (I == NST - 1) { asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(o[0]), "+v"(o[1]), "+v"(o[2])); }
+            if (I == NST - 1) { asm volatile("" : "+v"(s[0]), "+v"(s[1])); }
             return;
 #endif
             compute(ic);
@@ -635,12 +642,11 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
         stage(std::integral_constant<int, 14>{}); stage(std::integral_constant<int, 15>{});
         stage(std::integral_constant<int, 16>{}); stage(std::integral_constant<int, 17>{});
         stage(std::integral_constant<int, 18>{}); stage(std::integral_constant<int, 19>{});
-        stage(std::integral_constant<int, 20>{}); stage(std::integral_constant<int, 21>{});
     };
     // X(q): online softmax over the 64 keys of key row q (both tiles share the row bias th; the column bias is per tile)
     auto X = [&](float th) {
 #ifdef CVLM_G64_NOX
-        asm volatile("" : "+v"(ph[0][0]), "+v"(ph[1][1]), "+v"(pl[0][0]), "+v"(pl[1][1]));   // probe: no VALU phase
+        asm volatile("" : "+v"(xh[0][0]), "+v"(xh[1][1]), "+v"(xl[0][0]), "+v"(xl[1][1]));   // probe: no VALU phase
         return;
 #endif
         f32x2 z[2][8];
@@ -669,24 +675,32 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
         }
         l_run = l_run * alpha + ((acc0.x + acc0.y) + (acc1.x + acc1.y));
         if (!__all(m_new == m_run)) {
+            // the O^T tiles hold queries (lane & 15) + 16 qb: this lane's own factor serves one block, the lane 16 away holds the other
+            const auto ax = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, alpha), __builtin_bit_cast(unsigned, alpha), false, false);
+            const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
 #pragma unroll
-            for (int n = 0; n < ND; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
         }
         m_run = m_new;
+        // P (hi, lo): the first eight values of a tile (keys {0-3, 8-11} + 4 half) and the last eight ({16-19, 24-27} + 4 half)
+        // of every lane, register by register through v_permlane16_swap: the first result is the B operand of query block 0
+        // (lanes 0-15 / 32-47 keep their first eight, lanes 16-31 / 48-63 receive the last eight of the lane 16 below), the
+        // second that of query block 1.  Key order of the 32 k-slots: transpose_v_kernel stores V^T to match.
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const f32x2 v = z[e][4 * k2 + p];
-                    const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
-                    const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(v.x - (float)h[0], v.y - (float)h[1]));
-                    ph[e][k2][2 * p] = h[0]; ph[e][k2][2 * p + 1] = h[1];
-                    pl[e][k2][2 * p] = l[0]; pl[e][k2][2 * p + 1] = l[1];
-                }
+            for (int p = 0; p < 4; ++p) {
+                const f32x2 v0 = z[e][p], v1 = z[e][4 + p];
+                const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
+                const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
+                const half2v f0 = __builtin_bit_cast(half2v, h0), f1 = __builtin_bit_cast(half2v, h1);
+                const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)f0[0], v0.y - (float)f0[1]));
+                const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)f1[0], v1.y - (float)f1[1]));
+                const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
+                const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+                xh[e][0][p] = (unsigned)rh[0]; xh[e][1][p] = (unsigned)rh[1];
+                xl[e][0][p] = (unsigned)rl[0]; xl[e][1][p] = (unsigned)rl[1];
+            }
     };
 
     // ---- every wave runs  QK(pair 0) | X(0) Y(0) | X(1) Y(1) | ...  with Y(q) = PV(pair q), QK(pair q+1); group B one
@@ -709,13 +723,13 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
         if (trace) c0 = wall_clock64();
         if (grpB && q + 1 < NPAIR) { issue_next(oth); issue_next(oth + 1); }
         X(Tq[q]);
-        if (trace) { asm volatile("" ::"v"(ph[0][0]), "v"(pl[1][1])); c1 = wall_clock64(); }
+        if (trace) { asm volatile("" ::"v"(xh[0][0]), "v"(xl[1][1])); c1 = wall_clock64(); }
         if (!grpB) wait_vm<0>();
         phase_barrier();
         if (trace) c2 = wall_clock64();
         if (!grpB && q + 2 < NPAIR) { issue_next(cur); issue_next(cur + 1); }
         Y(cur, oth);                                                 // the last scores (pair NPAIR) are computed and dropped
-        if (trace) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][0]), "v"(o[2][0])); c3 = wall_clock64(); }
+        if (trace) { asm volatile("" ::"v"(s[0][0]), "v"(s[1][0]), "v"(o[4][1][0])); c3 = wall_clock64(); }
         if (grpB) wait_vm<0>();
         phase_barrier();
         if (trace) { const unsigned long long c4 = wall_clock64(); tr_x += c1 - c0; tr_xb += c2 - c1; tr_y += c3 - c2; tr_yb += c4 - c3; }
@@ -724,22 +738,23 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
 
     const float l_tot = half_swap_sum(l_run);
     const float inv = 1.0f / l_tot;
-    const int64_t orow = ((int64_t)b * S + qslot) * D + head * HD;
-    half_t* oh = (half_t*)g.out_hi + orow;
-    half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
+    const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
+    const float invq[2] = {__builtin_bit_cast(float, (unsigned)ix[0]), __builtin_bit_cast(float, (unsigned)ix[1])};
 #pragma unroll
-    for (int n = 0; n < ND; ++n)
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qs2 = blockIdx.x * 256 + wave * 32 + 16 * qb + (lane & 15);
+        const int64_t orow = ((int64_t)b * S + qs2) * D + head * HD + 4 * (lane >> 4);
+        half_t* oh = (half_t*)g.out_hi + orow;
+        half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int d = 32 * n + 8 * rg + 4 * half;
-            if (d < HD) {
-                half_t h[4], l4[4];
+        for (int n = 0; n < NDB; ++n) {
+            half_t h[4], l4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) split_h2(o[n][4 * rg + j] * inv, h[j], l4[j]);
-                *(half4*)(oh + d) = half4{h[0], h[1], h[2], h[3]};
-                if (ol) *(half4*)(ol + d) = half4{l4[0], l4[1], l4[2], l4[3]};
-            }
+            for (int j = 0; j < 4; ++j) split_h2(o[n][qb][j] * invq[qb], h[j], l4[j]);
+            *(half4*)(oh + 16 * n) = half4{h[0], h[1], h[2], h[3]};
+            if (ol) *(half4*)(ol + 16 * n) = half4{l4[0], l4[1], l4[2], l4[3]};
         }
+    }
     if (trace && lane == 0) {
         unsigned long long* o8 = trace + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
         o8[0] = tr_pro; o8[1] = tr_x; o8[2] = tr_xb; o8[3] = tr_y; o8[4] = tr_yb; o8[5] = wall_clock64() - tr_start;
@@ -747,7 +762,9 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
     }
 }
 
-// V [key][dim] (as the qkv GEMM leaves it) -> V^T [b][head][dim][key'], both planes; 64 keys x 80 dims per workgroup
+// V [key][dim] (as the qkv GEMM leaves it) -> V^T [b][head][dim][key'], both planes; 64 keys x 80 dims per workgroup.
+// ORDER16: key order of the 16x16x32 P.V operands (both kernels above), else that of 32x32x16 operands (round 2; kept for A/B builds).
+template <bool ORDER16>
 __global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g, half_t* __restrict__ vt_hi,
                                                           half_t* __restrict__ vt_lo) {
     constexpr int HD = 80, TP = 88;                                  // LDS row pitch in halves
@@ -764,12 +781,20 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g
     half_t* dst[2] = {vt_hi, vt_lo};
     for (int u = tid; u < 2 * HD * 8; u += 256) {
         const int pl = u / 640, d = (u % 640) / 8, c8 = u % 8;
-        // keys are stored in the order the P fragments hold them: element j of k-half h of a 16-key step is key
-        // (j & 3) + 8 (j >> 2) + 4 h (the row map of the 32x32 accumulator, which becomes the B operand unchanged)
-        const int g16 = c8 >> 1, h = c8 & 1;
         half8 v;
+        if (ORDER16) {
+            // 32-key tile e = c8 >> 2, key group gq = c8 & 3 of the 16x16x32 B operand: k-slot j of the group is key
+            // (j & 3) + 8 (j >> 2) + 16 (gq & 1) + 4 (gq >> 1) -- what the v_permlane16_swap of the 32x32 score layout leaves there
+            const int e = c8 >> 2, gq = c8 & 3;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = tile[pl][(16 * g16 + (j & 3) + 8 * (j >> 2) + 4 * h) * TP + d];
+            for (int j = 0; j < 8; ++j) v[j] = tile[pl][(32 * e + (j & 3) + 8 * (j >> 2) + 16 * (gq & 1) + 4 * (gq >> 1)) * TP + d];
+        } else {
+            // keys are stored in the order the P fragments hold them: element j of k-half h of a 16-key step is key
+            // (j & 3) + 8 (j >> 2) + 4 h (the row map of the 32x32 accumulator, which becomes the B operand unchanged)
+            const int g16 = c8 >> 1, h = c8 & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = tile[pl][(16 * g16 + (j & 3) + 8 * (j >> 2) + 4 * h) * TP + d];
+        }
         *(half8*)(dst[pl] + (((int64_t)b * g.heads + head) * HD + d) * S + s0 + c8 * 8) = v;
     }
 }
@@ -798,10 +823,10 @@ static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
     const size_t plane = (size_t)g.B * g.heads * 80 * S;
     if (!g.workspace || g.workspace_bytes < cvlm_attention_global64_pp_workspace_bytes(g)) return CVLM_E_WORKSPACE;
     half_t* vt = (half_t*)g.workspace;
-    hipLaunchKernelGGL(transpose_v_kernel, dim3(S / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
+    static const int pair = [] { const char* e = getenv("CVLM_ATTN_G64_PAIR"); return e ? atoi(e) : 1; }();
+    hipLaunchKernelGGL(transpose_v_kernel<true>, dim3(S / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
     CVLM_CHECK_LAUNCH();
     if constexpr (L == 64) {
-        static const int pair = [] { const char* e = getenv("CVLM_ATTN_G64_PAIR"); return e ? atoi(e) : 1; }();
         if (pair) {
             constexpr int smem2 = 4 * (2 * 5632) + 4 * (2 * 6144) + 256 * (L + 1) * 4;
             static bool attr2[16] = {};

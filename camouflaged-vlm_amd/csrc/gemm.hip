@@ -25,6 +25,8 @@
 namespace {
 
 constexpr int BK_MIN = 32;
+constexpr int SK_COUNTER0 = 4 * 128 + 2;        // split-K arrival counters live behind the tail words and the two error words
+constexpr int SK_MAX_TILES = 1024 - SK_COUNTER0;  // ... in the first 4-KiB page of the workspace
 constexpr float LN_FOLD_MAX_RATIO = 128.f;      // |row mean| / row sigma the LayerNorm-folded epilogue accepts (include/cvlm.h)
 
 // chunk permutation g(q), q = (row >> 2) & 3 (derived for the ds_read_b128 lane groups)
@@ -42,6 +44,7 @@ struct GemmParams {
     // and raise `flags` (chain: part k adds part k-1's running sum), part S-1 (highest block index) runs the epilogue.
     int tail_rem, tail_split;
     int total_blocks;  // PERSIST: workgroup b walks ids b, b + gridDim.x, ... < total_blocks
+    int sk_parts;      // SK kernels: K-parts per tile (grid = tiles x sk_parts)
     float* ws;
     unsigned* flags;   // [tail_rem][4] arrival words (1 when ready; the consumer puts 0 back), then error words at [4 * 128] (abandoned hand-offs), [4 * 128 + 1] (LayerNorm-fold rows out of range)
 #ifdef CVLM_PROBES
@@ -60,8 +63,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // CONV (2-stage loop): A is an NHWC image (conv_h x conv_w x conv_c per batch item, lda = conv_c) and the K axis runs
 // over the 9 taps of a 3x3 / pad 1 / stride 1 convolution, k = (ky*3 + kx)*C + c: the gather of im2col happens in the
 // DMA source addresses (a tap outside the image reads 16 zero bytes), nothing is materialised.
-template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1, bool CONV = false>
+// SK (small grids: one image, the CLIP towers at M = 581): EVERY tile is cut into p.sk_parts K-parts, one workgroup each.  A part
+// stores its fp32 accumulators as a slab in the workspace and counts itself in; the part that arrives LAST (an atomic counter,
+// no polling: safe whatever else shares the chip) adds the slabs of all parts in index order -- its own included, read back
+// like the others, so the order of the fp32 additions does not depend on who was last -- and runs the epilogue.
+template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1, bool CONV = false,
+          bool SK = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
+    static_assert(!SK || (!PERSIST && !CONV && NSTAGE != 5), "split-K form: plain tile loops only");
     static_assert(!PERSIST || NSTAGE == 5, "persistent form exists for the staggered 256^2 loop only");
     static_assert(!CONV || (NSTAGE == 2 && BK == 32), "implicit 3x3 convolution: 2-stage loop, 32-wide K-tiles");
     constexpr int WROWS = MT * 16;                                  // activation rows per wave
@@ -103,6 +112,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                          int64_t lda_, int64_t ldw_, int M_, int N_) {
         // tile coordinates: XCD-aware bijective remap of the 1-D tile id (8 XCDs, round-robin dispatch)
         kpart = 0; kparts = 1; tail_j = 0;
+        if (SK) {                                                        // parts-major: all part-0 workgroups first
+            kparts = p.sk_parts;
+            kpart = pid / ntiles;
+            pid -= kpart * ntiles;
+            tail_j = pid;                                                // slab / counter index of the tile
+        }
         if (NSTAGE == 5 && !PERSIST && p.tail_rem > 0 && pid >= ntiles - p.tail_rem) {
             const int j = pid - (ntiles - p.tail_rem);
             kparts = p.tail_split;
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             }
         }
         nk = g.K / BK;
-        if (NSTAGE == 5 && kparts > 1) {                                 // this workgroup's share of the K-tiles
+        if ((NSTAGE == 5 || SK) && kparts > 1) {                         // this workgroup's share of the K-tiles
             const int base = nk / kparts, extra = nk - base * kparts;
             const int k0 = kpart * base + (kpart < extra ? kpart : extra);
             nk = base + (kpart < extra ? 1 : 0);
@@ -508,7 +523,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 int spins = 0, bad = 0;
                 while (__hip_atomic_load(&p.flags[tail_j * 4 + kpart - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > (1 << 22)) { atomicAdd(&p.flags[4 * 128], 1u); bad = 1; break; }
+                    if (++spins > (1 << 22)) {
+                        // give up: mark the word ABANDONED (2) so that the late producer cleans it instead of leaving a stale
+                        // "ready" behind for the next launch; if the slab arrived in this very moment, take it after all
+                        unsigned expect = 0u;
+                        if (__hip_atomic_compare_exchange_strong(&p.flags[tail_j * 4 + kpart - 1], &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT) || expect != 1u) {
+                            atomicAdd(&p.flags[4 * 128], 1u);
+                            bad = 1;
+                        }
+                        break;
+                    }
                 }
                 tail_gave_up = bad;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -554,10 +579,55 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(&p.flags[tail_j * 4 + kpart], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // 0 -> 1 (ready); a consumer that gave up left 2 (abandoned): put the word back to 0, nobody will read this slab
+                unsigned expect = 0u;
+                if (!__hip_atomic_compare_exchange_strong(&p.flags[tail_j * 4 + kpart], &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT))
+                    __hip_atomic_store(&p.flags[tail_j * 4 + kpart], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             m_lim = 0;
         }
+    }
+    if (SK && kparts > 1) {
+        constexpr int SLAB4 = BM * BN / 4;                               // float4 per slab, accumulator layout as above
+        int lane_x = lane;
+        asm volatile("" : "+v"(lane_x));
+        float4* mine = (float4*)p.ws + ((size_t)tail_j * kparts + kpart) * SLAB4 + (size_t)wave * MT * 4 * 64;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const floatx4 c = acc[mt][nt];
+                mine[(mt * 4 + nt) * 64 + lane_x] = make_float4(c[0], c[1], c[2], c[3]);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __shared__ int sk_last;
+        __syncthreads();                                                 // every wave's slab stores have been issued and retired
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned old = __hip_atomic_fetch_add(&p.flags[SK_COUNTER0 + tail_j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(kparts - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // every part has counted itself: the word goes back to 0 for the next launch on this workspace
+                __hip_atomic_store(&p.flags[SK_COUNTER0 + tail_j], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            sk_last = last;
+        }
+        __syncthreads();
+        if (!sk_last) return;
+        const float4* slab = (const float4*)p.ws + (size_t)tail_j * kparts * SLAB4 + (size_t)wave * MT * 4 * 64 + lane_x;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float4 t = slab[(mt * 4 + nt) * 64];
+                for (int q = 1; q < kparts; ++q) {                       // index order: the same bits whoever arrived last
+                    const float4 v = slab[(size_t)q * SLAB4 + (mt * 4 + nt) * 64];
+                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                }
+                acc[mt][nt] = floatx4{t.x, t.y, t.z, t.w};
+            }
     }
     auto trace_end = [&]() {
 #ifdef CVLM_PROBES
@@ -1048,6 +1118,12 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     }
     GemmParams p;
     p.a = g;
+    if (fold || h2res) {
+        // these launches have no f32 output, no f32 residual and one problem: whatever the caller left in the fields that describe
+        // them must not send the kernel to the scalar epilogue, which knows neither form (it would return rc 0 and wrong numbers)
+        p.a.ldo = p.a.stride_o = p.a.ldr = p.a.stride_r = p.a.stride_oh = 0;
+        p.a.stride_a = p.a.stride_w = 0;
+    }
     if (p.a.batch <= 0) p.a.batch = 1;
     if (p.a.out_scale == 0.f) p.a.out_scale = 1.f;
     // tuning knobs, read once per process.  A process started with CVLM_GEMM_VARIANT_LIVE=1 (tests/conftest.py,
@@ -1110,6 +1186,84 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             variant = (c2 < c1) ? 2 : 1;
         }
     }
+    // ---- small grids: one image (M = 4096 in the ViT-H blocks, 581 in the CLIP towers -- the reference's own call pattern,
+    // demo.py / DataLoader batch_size = 1) and everything below.  The constants of the model above were fitted on grids that fill
+    // the chip several times; here a workgroup often has a CU (or the L2) to itself and runs up to twice as fast, hand-offs are
+    // cheap (every K-part is resident at once) and a fourth form exists: split-K over ALL tiles of a 128^2 grid (SK kernel).
+    // Per-workgroup cost = t0 + K * c(fill), c rising linearly with the fill of the workgroup slots; fitted on the eight shapes of
+    // tools/ab_gemm.py SHAPES=b1 (profiles/r03_ab_gemm_b1.log: the model picks the measured winner for each).
+    p.sk_parts = 1;
+    int small_tail_S = 0;                                             // > 0: K-parts of the 256^2 tail chain chosen here
+    static int sk_env = env_int("CVLM_GEMM_SK", 1), small_env = env_int("CVLM_GEMM_SMALL", 1);
+    if (live_env) { sk_env = env_int("CVLM_GEMM_SK", 1); small_env = env_int("CVLM_GEMM_SMALL", 1); }
+    if (g.split == 3 && !conv && p.a.batch == 1 && g.M <= 4096 && small_env != 0 && (variant_env == 0 || (variant_env == 1 && sk_env > 1))) {
+        const double K = (double)g.K;
+        const long t1 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+        const long t2 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+        const long t5 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        auto fillc = [](double lo, double hi, double wgs, double slots) { const double f = wgs / slots; return lo + (hi - lo) * (f < 1.0 ? f : 1.0); };
+        auto over = [](double wgs, double slots) { const double r = wgs / slots; return r > 1.0 ? r : 1.0; };
+        const double m1 = 4.0 + K * fillc(0.021, 0.054, (double)t1, 512.0) * over((double)t1, 512.0);
+        const double m2 = 4.0 + K * fillc(0.028, 0.047, (double)t2, 256.0) * over((double)t2, 256.0);
+        // 256^2 tiles: full rounds at the fitted tile time, the last round whole or cut into S chained K-parts
+        const long full5 = t5 / 256, rem5 = t5 % 256;
+        double m7 = (double)full5 * (14.0 + 0.0685 * K);
+        int tailS = 0;
+        if (rem5 > 0) {
+            double last = (14.0 + 0.0685 * K) * (0.75 + 0.25 * (double)rem5 / 256.0);
+            if (tail_env && have_ws && rem5 <= 128) {
+                const int smax = 256 / rem5 < 4 ? (int)(256 / rem5) : 4;
+                for (int S = 2; S <= smax; ++S) {
+                    if (g.K / 32 < 4 * S) break;
+                    const double f = (double)(rem5 * S) / 256.0;
+                    const double t = (14.0 + 0.0685 * K / S) * (0.75 + 0.25 * (f < 1.0 ? f : 1.0)) + 6.0 + 4.0 * S;
+                    if (t < 0.95 * last) { last = t; tailS = S; }
+                }
+            }
+            m7 += last;
+        }
+        // split-K over every 128^2 tile: S x (slab write + read) of the whole output is what it costs
+        int skS = 1;
+        double msk = 1e30;
+        if (have_ws && sk_env != 0 && t1 <= SK_MAX_TILES) {
+            for (int S = 2; S <= 8; ++S) {
+                if (g.K / 32 < 4 * S || (size_t)t1 * S * 128 * 128 * sizeof(float) > TAIL_WS_BYTES) break;
+                const double wg = (double)(t1 * S);
+                const double t = 4.0 + (K / S) * fillc(0.021, 0.054, wg, 512.0) * over(wg, 512.0) + 6.0 + 2.0 * S + 0.052 * wg;
+                if (t < msk) { msk = t; skS = S; }
+            }
+        }
+        if (sk_env > 1) {                                                // forced (A/B tools, tests): the same limits
+            const bool okS = have_ws && sk_env <= 8 && t1 <= SK_MAX_TILES && g.K / 32 >= 4 * sk_env &&
+                             (size_t)t1 * sk_env * 128 * 128 * sizeof(float) <= TAIL_WS_BYTES;
+            skS = okS ? sk_env : 1;
+            msk = okS ? 0.0 : 1e30;
+        }
+        const bool fast_ok = true;
+        (void)fast_ok;
+        if (variant_env == 0) {
+            double best = m1;
+            variant = 1;
+            if (m2 < best) { best = m2; variant = 2; }
+            if (m7 < best) { best = m7; variant = 5; small_tail_S = tailS > 0 ? tailS : -1; }
+            if (skS > 1 && msk < 0.9 * best) { best = msk; variant = 1; p.sk_parts = skS; }
+        } else if (skS > 1) {
+            p.sk_parts = skS;
+        }
+        if (p.sk_parts > 1) {
+            p.flags = (unsigned*)g.workspace;
+            p.ws = (float*)((unsigned char*)g.workspace + TAIL_FLAG_BYTES);
+            p.nbx = (g.N + 127) / 128; p.nby = (g.M + 127) / 128;
+            constexpr int smem_sk = 2 * 2 * (128 + 128) * 32 * 2;
+            auto ksk = gemm_nt_kernel<3, 2, 2, 2, 32, 0, 4, false, -1, false, true>;
+            static bool attr_sk[16] = {};
+            if (cvlm_first_on_device(attr_sk))
+                (void)hipFuncSetAttribute((const void*)ksk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);
+            hipLaunchKernelGGL(ksk, dim3(p.nbx * p.nby * p.sk_parts, 1), dim3(256), smem_sk, s, p);
+            CVLM_CHECK_LAUNCH();
+            return 0;
+        }
+    }
 #define CVLM_LAUNCH(SPLIT, WM, WN, NS) CVLM_LAUNCH_D(SPLIT, WM, WN, NS, 32, 0, 4)
 #define CVLM_LAUNCH_D(SPLIT, WM, WN, NS, BKT, DBG, MT)                                                        \
     do {                                                                                                      \
@@ -1157,7 +1311,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         if (variant == 7 && tail_env && have_ws && p.a.batch == 1) {
             const long T = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
             const int rem = (int)(T % 256);
-            const int S = tail_parts(rem, g.K);
+            const int S = small_tail_S > 0 ? small_tail_S : (small_tail_S < 0 ? 1 : tail_parts(rem, g.K));   // small grids: chosen above
             if (S >= 2) {
                 p.tail_rem = rem; p.tail_split = S;
                 p.flags = (unsigned*)g.workspace;
@@ -1168,9 +1322,10 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         // Persistent form of the 256^2 kernel: one workgroup per CU walks the tile list.  Not for launches with tail parts:
         // their hand-off chain relies on in-order dispatch (every producer is resident or done before its consumer
         // starts), which a persistent grid sharing the chip with another stream cannot promise.
-        const bool lds_staged = g.ps_c2 == 0 && (g.N & 7) == 0 && (g.hm_S == 0 || ((g.hm_hd & 7) == 0 && g.hm_S >= 128)) &&
-                                (g.ldo & 3) == 0 && (g.stride_o & 3) == 0 && (g.ldr & 3) == 0 && (g.stride_r & 3) == 0 &&
-                                (g.ldoh & 7) == 0 && (g.stride_oh & 7) == 0;
+        const cvlm_gemm_args& ga = p.a;                                  // the sanitised copy (fold / h2-residual launches)
+        const bool lds_staged = ga.ps_c2 == 0 && (ga.N & 7) == 0 && (ga.hm_S == 0 || ((ga.hm_hd & 7) == 0 && ga.hm_S >= 128)) &&
+                                (ga.ldo & 3) == 0 && (ga.stride_o & 3) == 0 && (ga.ldr & 3) == 0 && (ga.stride_r & 3) == 0 &&
+                                (ga.ldoh & 7) == 0 && (ga.stride_oh & 7) == 0;
         if (variant == 7 && persist_env && (variant_env == 0 || variant_env == 7) && lds_staged && p.a.batch == 1) {
             static int cus_[16] = {};
             int dev = 0;

@@ -138,13 +138,15 @@ class _Base:
         self.device = device
         self.prec = precision
         self.ws = Workspace(device)
+        self.ksplit = True          # False: GEMMs get no workspace, i.e. no K-split of any kind: the summation order is independent of M
 
     def gemm(self, a: H2, lin: Linear, M: int, **kw) -> None:
         kw.setdefault("split", self.prec.gemm)
         alpha = kw.pop("alpha", 1.0)
         if "bias" not in kw:
             kw["bias"] = lin.bias
-        hip.gemm(a, lin.w, M, kw.pop("N", lin.N), lin.K, alpha=alpha * lin.alpha, workspace=self.ws.gemm_ws(), **kw)
+        hip.gemm(a, lin.w, M, kw.pop("N", lin.N), lin.K, alpha=alpha * lin.alpha,
+                 workspace=self.ws.gemm_ws() if self.ksplit else None, **kw)
 
     def attention(self, qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, **kw) -> None:
         hip.attention(qkv, out, B, S, heads, hd,
@@ -844,13 +846,19 @@ class ClipModel(_Base):
         full = torch.cat([pre, self.ctx.unsqueeze(0).expand(n, -1, -1), suf], dim=1)[:, :L].contiguous()
         x = torch.empty(n, L, Wd, device=self.device)
         hip.add_rows(full, self.tpos[:L].contiguous(), L, n * L, Wd, out_f32=x)
-        self._blocks(x, self.tblocks, n, L, Wd, c.text_heads, self.deep_text, 1, causal=True)
-        rows_f = torch.empty(n, Wd, device=self.device)
-        hip.gather_rows(x, n, L, Wd, torch.tensor(eot, dtype=torch.int32, device=self.device), 0, rows_f)
-        rh = H2.empty(n, Wd, device=self.device)
-        hip.layernorm(rows_f, *self.ln_final, 1e-5, n, Wd, out_h2=rh)
-        out = torch.empty(n, c.embed_dim, device=self.device)
-        self.gemm(rh, self.tproj, n, out_f32=out)
+        # A rank's shard must give the bits of the full bank: no K-split here -- tail chain and split-K pick their
+        # number of parts from M = prompts x positions, which differs between a shard and the whole (runs once per weight load)
+        self.ksplit = False
+        try:
+            self._blocks(x, self.tblocks, n, L, Wd, c.text_heads, self.deep_text, 1, causal=True)
+            rows_f = torch.empty(n, Wd, device=self.device)
+            hip.gather_rows(x, n, L, Wd, torch.tensor(eot, dtype=torch.int32, device=self.device), 0, rows_f)
+            rh = H2.empty(n, Wd, device=self.device)
+            hip.layernorm(rows_f, *self.ln_final, 1e-5, n, Wd, out_h2=rh)
+            out = torch.empty(n, c.embed_dim, device=self.device)
+            self.gemm(rh, self.tproj, n, out_f32=out)
+        finally:
+            self.ksplit = True
         return out
 
     def set_text_bank(self, text_feat: torch.Tensor, bank: torch.Tensor, split: str = "test") -> None:

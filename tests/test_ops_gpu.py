@@ -126,6 +126,58 @@ def test_gemm_tail_split(hip, M, N, K, why, monkeypatch):
     assert int(ws[:2048].view(torch.int32).abs().sum()) == 0                           # hand-off words are back to zero
 
 
+@pytest.mark.parametrize("M,N,K,parts", [(581, 1024, 4096, 8), (581, 3072, 1024, 4), (1162, 1024, 1024, 2), (4096, 1280, 5184, 3),
+                                          (300, 264, 512, 4)])
+def test_gemm_split_k_small_grids(hip, monkeypatch, M, N, K, parts):
+    """Split-K form for small grids (one image, CLIP at M = 581): every 128^2 tile cut into K-parts, the last arriver adds the
+    slabs in index order.  Same values as the whole-tile launch up to fp32 summation order, bit-identical from run to run
+    (the order does not depend on which part arrived last), arrival counters back at zero, every epilogue form."""
+    from camouflaged_vlm_amd.engine import LnLinear
+    a, w, bias, res = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33), rnd(M, N, seed=34)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    ref = A.float().cpu().double() @ W.float().cpu().double().t() + bias.double() + res.double()
+    ws = hip.new_gemm_workspace("cuda")
+    outs = []
+    for sk in ("0", str(parts), str(parts), "1"):                                   # off, forced, forced again, automatic
+        monkeypatch.setenv("CVLM_GEMM_SK", sk)
+        o = torch.full((M, N), float("nan"), device="cuda")
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), residual=res.cuda(), out_f32=o, workspace=ws)
+        torch.cuda.synchronize()
+        outs.append(o)
+        assert relerr(o.cpu().double(), ref) < 3e-6, sk
+    assert torch.equal(outs[1], outs[2])                                             # fixed summation order
+    assert float((outs[0] - outs[1]).abs().max() / ref.abs().max()) < 4e-6
+    assert hip.gemm_workspace_errors(ws) == 0
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0                         # counters and hand-off words back to zero
+    # LayerNorm-folded consumer + h2-residual producer through the split-K kernel (N % 8 == 0 shapes)
+    if N % 8 == 0 and K % 64 == 0:
+        XS = 0.25
+        x = rnd(M, K, seed=35) * 2.0
+        gamma, beta = 1.0 + 0.1 * rnd(K, seed=36), 0.05 * rnd(K, seed=37)
+        xh, st = hip.H2.empty(M, K), torch.empty(hip.stats_pieces(K), M, 2, device="cuda")
+        hip.row_stats_split(x.cuda(), XS, xh, st, M, K)
+        lin = LnLinear(w, bias, gamma, beta, "cuda")
+        got = {}
+        for sk in ("0", str(parts)):
+            monkeypatch.setenv("CVLM_GEMM_SK", sk)
+            o = hip.H2.empty(M, N)
+            o.t.fill_(float("nan"))
+            st_out = torch.full((hip.stats_pieces(N), M, 2), float("nan"), device="cuda")
+            hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=1, out_h2=o, ln_fold=(st, lin.colsum, 1e-6, K),
+                     workspace=ws)
+            o2 = hip.H2(hip.H2.pack(res * XS).t.cuda())
+            hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o2, residual_h2=(o2, 1.0 / XS), out_scale=XS, row_stats=st_out, workspace=ws)
+            got[sk] = (o.float().cpu().double(), o2.float().cpu().double() / XS, st_out.cpu().double())
+        z = F.gelu(F.layer_norm(xh.float().cpu().double() / XS, (K,), gamma.double(), beta.double(), 1e-6) @ w.double().t() + bias.double())
+        assert float((got[str(parts)][0] - z).abs().max()) < 2e-5 * max(1.0, float(z.abs().max()))
+        assert float((got[str(parts)][0] - got["0"][0]).abs().max()) < 1e-5
+        ref2 = ref - res.double() + hip.H2.pack(res * XS).float().double() / XS
+        assert relerr(got[str(parts)][1], ref2) < 3e-6
+        s_ref, s_mag = piece_stats_ref(ref2)
+        assert float(((got[str(parts)][2] - s_ref).abs() / s_mag).max()) < 5e-6
+        assert hip.gemm_workspace_errors(ws) == 0
+
+
 @pytest.mark.parametrize("M,D,N,act", [(700, 160, 480, 0), (4096 + 40, 1280, 768, 1), (520, 1024, 264, 2)])
 def test_gemm_layernorm_fold_and_h2_residual(hip, M, D, N, act):
     """The pair of epilogue forms that keep a pre-norm residual stream in h2 (include/cvlm.h, ABI 3):

@@ -7,7 +7,7 @@ from camouflaged_vlm_amd.engine import Cascade, Precision
 import camouflaged_vlm_amd as cv
 sys.path.insert(0, cv.DROPIN_DIR)
 from cocotrainers.mapleAlphaCLIP import gather_text_features
-g, c, B, dev = spec.DEMO_SAM, spec.DEMO_CLIP, 8, torch.device("cuda", 0)
+g, c, B, dev = spec.DEMO_SAM, spec.DEMO_CLIP, int(os.environ.get("BATCH", "8")), torch.device("cuda", 0)
 sd = {k: torch.from_numpy(v) for k, v in synth.make_full_state_dict(g, c).items()}
 cas = Cascade(sd, g, c, dev, Precision.named("exact"))
 eot = host.eot_for_classes(host.ovcamo_constants()["names_test"].tolist())[:c.n_cls_test]
@@ -22,6 +22,7 @@ def timed(fn, n=10):
     return (time.perf_counter() - t0) / n * 1e3, out
 ms_eager, ref = timed(lambda: cas.cascade(inp, ci, cm, pipelined=False))
 ms_pipe, _ = timed(lambda: cas.cascade(inp, ci, cm, pipelined=True))
+cas.flush()
 torch.cuda.synchronize()
 s = torch.cuda.Stream(device=dev)
 s.wait_stream(torch.cuda.current_stream())
@@ -35,6 +36,7 @@ with torch.cuda.graph(graph):
 torch.cuda.synchronize()
 ms_graph, _ = timed(lambda: graph.replay())
 ok = torch.equal(out[1], ref[1]) and float((out[0] - ref[0]).abs().max()) < 2e-4 and bool(torch.isfinite(out[0]).all())
+print(f"batch {B}")
 print(f"eager, plain stream semantics : {ms_eager:8.2f} ms/step")
 print(f"hipGraph replay of that step  : {ms_graph:8.2f} ms/step   (outputs match eager: {ok}; hand-off errors {cas.encoder.ws.gemm_errors()})")
 print(f"eager, pipelined serving loop : {ms_pipe:8.2f} ms/step   (bench.py's loop)")

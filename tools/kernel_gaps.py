@@ -10,9 +10,24 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 short = lambda n: re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", ""))[:60]
-# middle third of the trace = steady-state steps (the head holds weight uploads, the tail the parity check and CPU work)
+# middle third of the trace = steady-state steps (the head holds weight uploads, the tail the parity check and CPU work);
+# "tail:<frac>" as second argument: the last <frac> of the kernels instead (short runs whose head is mostly uploads)
 n = len(rows)
 part = rows[n // 3: n * 2 // 3]
+if len(sys.argv) > 2 and sys.argv[2].startswith("tail:"):
+    part = rows[int(n * (1.0 - float(sys.argv[2][5:]))):]
+    # per-kernel busy time, union over overlapping streams
+    ivs = sorted((s, e) for s, e, _ in part)
+    cover, cur_s, cur_e = 0, ivs[0][0], ivs[0][1]
+    for s, e in ivs[1:]:
+        if s > cur_e:
+            cover += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    cover += cur_e - cur_s
+    print(f"tail window: {len(part)} kernels, wall {(ivs[-1][1] - ivs[0][0]) / 1e6:.2f} ms, GPU busy (union of kernels) {cover / 1e6:.2f} ms, "
+          f"sum of kernel durations {sum(e - s for s, e in ivs) / 1e6:.2f} ms")
 busy = sum(e - s for s, e, _ in part)
 wall = part[-1][1] - part[0][0]
 gaps = collections.defaultdict(lambda: [0, 0])
