@@ -27,7 +27,6 @@ namespace {
 constexpr int BK_MIN = 32;
 constexpr int SK_COUNTER0 = 4 * 128 + 2;        // split-K arrival counters live behind the tail words and the two error words
 constexpr int SK_MAX_TILES = 1024 - SK_COUNTER0;  // ... in the first 4-KiB page of the workspace
-constexpr float LN_FOLD_MAX_RATIO = 128.f;      // |row mean| / row sigma the LayerNorm-folded epilogue accepts (include/cvlm.h)
 
 // chunk permutation g(q), q = (row >> 2) & 3 (derived for the ds_read_b128 lane groups)
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
@@ -718,74 +717,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             float cs8[8], b8[8];                                      // MODE 1: column sums / bias of this lane's 8 columns
             float ln_rs[MT][2], ln_c[MT][2];                          // MODE 1: rstd and mu * rstd of this lane's 2 * MT rows
             if (MODE == 1) {
-                const float ln_inv_d = 1.0f / (float)g.ln_D;
-                // Row statistics arrive as per-piece pairs (include/cvlm.h: ln_stats[p][m] = (sum, centred sum of squares) of
-                // columns [64p, 64p + 64) of row m, written with plain stores by the producer -- no atomics, no memset, fixed
-                // summation order).  The workgroup merges them once per tile: TPR threads per tile row add the even / odd pieces
-                // (the order does not depend on TPR), combine, and leave (rstd, mu * rstd) in LDS, from where every lane takes
-                // its 2 * MT rows.  v_rsq instead of an IEEE sqrt + divide (7 us per 256^2 tile in the first version).
-                constexpr int TPR = NWAVE * 64 / BM;
-                static_assert(TPR == 1 || TPR == 2, "row-statistics merge: one or two threads per tile row");
-                float2* sbuf = (float2*)(smem + (PERSIST ? 2 * STAGE : 0));
-                {
-                    const int r = tid / TPR, h = tid - r * TPR;
-                    int m = e_bm + r;
-                    m = m < g.M ? m : g.M - 1;
-                    const int P = (g.ln_D + 63) >> 6;
-                    const float2* sp = (const float2*)g.ln_stats + m;
-                    float tot = 0.f;
-                    if (TPR == 2) {
-                        float a = 0.f;
-                        for (int pc = h; pc < P; pc += 2) a += sp[(int64_t)pc * g.M].x;
-                        tot = a + __shfl_xor(a, 1, 64);
-                    } else {
-                        float a0 = 0.f, a1 = 0.f;
-                        for (int pc = 0; pc < P; pc += 2) a0 += sp[(int64_t)pc * g.M].x;
-                        for (int pc = 1; pc < P; pc += 2) a1 += sp[(int64_t)pc * g.M].x;
-                        tot = a0 + a1;
-                    }
-                    const float mu = tot * ln_inv_d;
-                    // M2 = sum_p m2_p + n_p * (s1_p / n_p - mu)^2   (pairwise merge of centred moments: no s2 / D - mu^2
-                    // cancellation for rows whose mean dwarfs their spread)
-                    auto part = [&](int pc) -> float {
-                        const float2 v = sp[(int64_t)pc * g.M];
-                        const int np = g.ln_D - (pc << 6) < 64 ? g.ln_D - (pc << 6) : 64;
-                        const float dm = v.x * (np == 64 ? 0.015625f : 1.0f / (float)np) - mu;
-                        return fmaf((float)np * dm, dm, v.y);
-                    };
-                    float m2 = 0.f;
-                    if (TPR == 2) {
-                        float a = 0.f;
-                        for (int pc = h; pc < P; pc += 2) a += part(pc);
-                        m2 = a + __shfl_xor(a, 1, 64);
-                    } else {
-                        float a0 = 0.f, a1 = 0.f;
-                        for (int pc = 0; pc < P; pc += 2) a0 += part(pc);
-                        for (int pc = 1; pc < P; pc += 2) a1 += part(pc);
-                        m2 = a0 + a1;
-                    }
-                    float rs = __builtin_amdgcn_rsqf(fmaxf(m2 * ln_inv_d, 0.f) + g.ln_eps);
-                    // Guaranteed range of the fold: alpha * acc - mu * colsum cancels |mu| / sigma of the operand format's 22 bits
-                    // (measured: error 4e-6 * |mu| / sigma per output).  A row beyond LN_FOLD_MAX_RATIO does not get a plausible
-                    // wrong value: its outputs become NaN and the workspace counts it (include/cvlm.h).
-                    if (fabsf(mu) * rs > LN_FOLD_MAX_RATIO) {
-                        rs = __builtin_nanf("");
-                        if (h == 0 && p.flags && e_bn == 0 && e_bm + r < g.M) atomicAdd(&p.flags[4 * 128 + 1], 1u);
-                    }
-                    if (h == 0) sbuf[r] = make_float2(rs, mu * rs);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                // all row statistics of the tile up front: one batch of 2 * MT loads of (rstd, mu * rstd) pairs per lane.  The pairs
+                // are merged from the producer's per-piece statistics by cvlm_ln_stats_merge between the two launches: merged
+                // inside this kernel (ten piece loads per thread, LDS exchange) the fold cost qkv / lin1 7-8 % -- the loads'
+                // latency sits between main loop and epilogue with nothing to hide it; read ready-made it costs 0.4 %
+                // (profiles/r03_ln_merge_probe.log).
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const float2 v = sbuf[wm * WROWS + mt * 16 + rowh + 8 * i];
+                        int m = mw + mt * 16 + rowh + 8 * i;
+                        m = m < g.M ? m : g.M - 1;
+                        const float2 v = *(const float2*)(g.ln_stats + 2 * (int64_t)m);
                         ln_rs[mt][i] = v.x;
                         ln_c[mt][i] = v.y;
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                            // sbuf aliases wave 0's staging slab
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const bool okc = nh + j < g.N;
@@ -1113,7 +1059,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         if (fold && h2res) return CVLM_E_BADARG;
         if (!g.out_hi || g.out_f32 || g.residual || g.ps_c2 > 0 || g.batch > 1) return CVLM_E_BADARG;
         if ((g.N & 7) || (g.ldoh & 7) || (g.hm_S > 0 && ((g.hm_hd & 7) || g.hm_S < 128))) return CVLM_E_UNSUPPORTED;
-        if (fold && (!g.ln_colsum || g.ln_D <= 0 || (g.act != ACT_NONE && g.act != ACT_GELU && g.act != ACT_QUICKGELU))) return CVLM_E_BADARG;
+        if (fold && (!g.ln_colsum || (g.act != ACT_NONE && g.act != ACT_GELU && g.act != ACT_QUICKGELU))) return CVLM_E_BADARG;
         if (h2res && (g.act != ACT_NONE || (g.res_hi && (!g.res_lo || (g.ldrh & 7))))) return CVLM_E_BADARG;
     }
     GemmParams p;
@@ -1143,7 +1089,6 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr;
     p.total_blocks = 0;
     const bool have_ws = g.workspace && g.workspace_bytes >= cvlm_gemm_workspace_bytes();
-    if (have_ws) p.flags = (unsigned*)g.workspace;                   // word 513: rows refused by the LayerNorm fold
     hipStream_t s = (hipStream_t)stream;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
     int variant = variant_env;

@@ -241,6 +241,49 @@ __global__ __launch_bounds__(256) void row_stats_split_kernel(const float* __res
     }
 }
 
+// Piece statistics -> the (rstd, mu * rstd) pair per row the LayerNorm-folded GEMM epilogue reads (include/cvlm.h).  One thread per
+// row; the pieces of a row are added in index order (bit-reproducible), as centred moments:
+//   mu = sum_p s1_p / D,   M2 = sum_p [ m2_p + n_p (s1_p / n_p - mu)^2 ],   rstd = 1 / sqrt(M2 / D + eps).
+// A row with |mu| * rstd > max_ratio is refused: its pair becomes NaN (every output of that row of the folded GEMM is NaN then)
+// and *refused (optional) counts it.
+__global__ __launch_bounds__(64) void ln_stats_merge_kernel(const float* __restrict__ pieces, int64_t piece_rows, int M, int D, float eps,
+                                                           float max_ratio, float* __restrict__ merged, unsigned* __restrict__ refused) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= M) return;
+    const int P = (D + 63) >> 6;
+    const float2* sp = (const float2*)pieces + m;
+    const float inv_d = 1.0f / (float)D;
+    auto centred = [&](float2 v, int pc, float mu) -> float {
+        const int np = D - (pc << 6) < 64 ? D - (pc << 6) : 64;
+        const float dm = v.x * (np == 64 ? 0.015625f : 1.0f / (float)np) - mu;
+        return fmaf((float)np * dm, dm, v.y);
+    };
+    float mu, m2 = 0.f;
+    constexpr int PMAX = 32;                                              // D <= 2048: every piece of the row in registers, one batch of loads
+    if (P <= PMAX) {
+        float2 v[PMAX];
+#pragma unroll
+        for (int pc = 0; pc < PMAX; ++pc) v[pc] = pc < P ? sp[(int64_t)pc * piece_rows] : make_float2(0.f, 0.f);
+        float tot = 0.f;
+#pragma unroll
+        for (int pc = 0; pc < PMAX; ++pc) tot += pc < P ? v[pc].x : 0.f;
+        mu = tot * inv_d;
+#pragma unroll
+        for (int pc = 0; pc < PMAX; ++pc) m2 += pc < P ? centred(v[pc], pc, mu) : 0.f;
+    } else {
+        float tot = 0.f;
+        for (int pc = 0; pc < P; ++pc) tot += sp[(int64_t)pc * piece_rows].x;
+        mu = tot * inv_d;
+        for (int pc = 0; pc < P; ++pc) m2 += centred(sp[(int64_t)pc * piece_rows], pc, mu);
+    }
+    float rs = __builtin_amdgcn_rsqf(fmaxf(m2 * inv_d, 0.f) + eps);
+    if (fabsf(mu) * rs > max_ratio) {
+        rs = __builtin_nanf("");
+        if (refused) atomicAdd(refused, 1u);
+    }
+    *(float2*)(merged + 2 * (int64_t)m) = make_float2(rs, mu * rs);
+}
+
 __global__ __launch_bounds__(256) void dense_pe_kernel(const float* __restrict__ gauss, int size, int C,
                                                        float* __restrict__ out) {
     const int half = C >> 1;
@@ -572,6 +615,16 @@ int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo
     if (stats_rows < M + (int64_t)(copies - 1) * dst_row_stride) return CVLM_E_BADARG;
     hipLaunchKernelGGL(row_stats_split_kernel, dim3((M + 3) / 4, copies), dim3(256), 0, (hipStream_t)stream, x, scale, (half_t*)out_hi,
                        (half_t*)out_lo, stats, M, D, dst_row_stride, stats_rows);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_ln_stats_merge(const float* pieces, int64_t piece_rows, int32_t M, int32_t D, float eps, float* merged, void* gemm_workspace,
+                        void* stream) {
+    if (!pieces || !merged || M <= 0 || D <= 0 || piece_rows < M) return CVLM_E_BADARG;
+    unsigned* refused = gemm_workspace ? (unsigned*)gemm_workspace + CVLM_WS_WORD_LN_REFUSED : nullptr;
+    hipLaunchKernelGGL(ln_stats_merge_kernel, dim3((M + 63) / 64), dim3(64), 0, (hipStream_t)stream, pieces, piece_rows, M, D, eps,
+                       (float)CVLM_LN_FOLD_MAX_RATIO, merged, refused);
     CVLM_CHECK_LAUNCH();
     return 0;
 }

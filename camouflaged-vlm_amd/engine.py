@@ -328,17 +328,19 @@ class SamEncoder(_Base):
         G, D, T = g.grid, g.embed_dim, g.grid * g.grid
         M, HK = B * T, g.mlp_dim + self.PK
         xh = ws.h2("xh", M, D)
-        # row statistics travel as per-64-column pieces written with plain stores (include/cvlm.h, ABI 5): nothing to zero
-        # between launches, and the folded LayerNorm is bit-reproducible from run to run
-        PC = hip.stats_pieces(D)
-        st1, st2 = ws.f32("ln_st1", PC, M, 2), ws.f32("ln_st2", PC, M, 2)
+        # Row statistics travel as per-64-column pieces written with plain stores (include/cvlm.h, ABI 5): nothing to zero
+        # between launches, no atomics -- the folded LayerNorm is bit-reproducible from run to run.  A 3-us kernel merges the
+        # pieces of a row into the (rstd, mu * rstd) pair the consuming GEMM's epilogue reads.
+        pcs, mrg = ws.f32("ln_pieces", hip.stats_pieces(D), M, 2), ws.f32("ln_merged", M, 2)
+        gws = self.ws.gemm_ws()
         self.gemm(feat, self.light[0], M, out_h2=prm, act=ACT_GELU)               # prompt of block 0 (:145)
         self.gemm(prm, self.shared, M, residual=x, out_f32=x)
-        hip.row_stats_split(x, X_SCALE, xh, st1, M, D)
+        hip.row_stats_split(x, X_SCALE, xh, pcs, M, D)
         inv = 1.0 / X_SCALE
         for i, blk in enumerate(self.blocks):
+            hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)
             self.gemm(xh, blk["qkv_f"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim), alpha=inv,
-                      ln_fold=(st1, blk["qkv_f"].colsum, 1e-6, D))
+                      ln_fold=(mrg, blk["qkv_f"].colsum))
             if blk["window"] > 0:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
                                pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
@@ -346,13 +348,14 @@ class SamEncoder(_Base):
             else:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
                                rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
-            self.gemm(att, blk["proj"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=st2)
+            self.gemm(att, blk["proj"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=pcs)
+            hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)
             self.gemm(xh, blk["lin1_f"], M, out_h2=hid, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE, alpha=inv,
-                      ln_fold=(st2, blk["lin1_f"].colsum, 1e-6, D))
+                      ln_fold=(mrg, blk["lin1_f"].colsum))
             if i + 1 < g.depth:
                 self.gemm(feat, self.light[i + 1], M, out_h2=hid_prm, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE)
                 self.gemm(hid, self.lin2cat[i], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
-                          alpha=1.0 / HID_SCALE, row_stats=st1)
+                          alpha=1.0 / HID_SCALE, row_stats=pcs)
             else:
                 self.gemm(hid, blk["lin2"], M, lda=HK, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
                           alpha=1.0 / HID_SCALE)
@@ -783,20 +786,22 @@ class ClipModel(_Base):
         M, inv = Bn * L, 1.0 / X_SCALE
         xh, qkv, att = ws.h2("vxh", M, Wd), ws.h2("vqkv", M, 3 * Wd), ws.h2("vatt", M, Wd)
         hid = ws.h2("vhid", M, 4 * Wd)
-        PC = hip.stats_pieces(Wd)
-        st1, st2 = ws.f32("vst1", PC, M, 2), ws.f32("vst2", PC, M, 2)
-        hip.row_stats_split(x.view(M, Wd), X_SCALE, xh, st1, M, Wd)
+        pcs, mrg = ws.f32("vln_pieces", hip.stats_pieces(Wd), M, 2), ws.f32("vln_merged", M, 2)
+        gws = self.ws.gemm_ws()
+        hip.row_stats_split(x.view(M, Wd), X_SCALE, xh, pcs, M, Wd)
         for i, blk in enumerate(self.vblocks):
             if 1 <= i <= len(self.deep_vis):
-                hip.row_stats_split(self.deep_vis[i - 1], X_SCALE, xh, st1, c.n_ctx, Wd, row0=first_row, copies=Bn,
+                hip.row_stats_split(self.deep_vis[i - 1], X_SCALE, xh, pcs, c.n_ctx, Wd, row0=first_row, copies=Bn,
                                     dst_row_stride=L)
-            self.gemm(xh, blk["inp_f"], M, out_h2=qkv, alpha=inv, ln_fold=(st1, blk["inp_f"].colsum, 1e-5, Wd))
+            hip.ln_stats_merge(pcs, M, Wd, 1e-5, mrg, gws)
+            self.gemm(xh, blk["inp_f"], M, out_h2=qkv, alpha=inv, ln_fold=(mrg, blk["inp_f"].colsum))
             self.attention(qkv, att, Bn, L, heads, Wd // heads, mode=0, causal=False, split_qk=pr.qk, split_pv=pr.pv)
-            self.gemm(att, blk["out"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=st2)
+            self.gemm(att, blk["out"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=pcs)
+            hip.ln_stats_merge(pcs, M, Wd, 1e-5, mrg, gws)
             self.gemm(xh, blk["fc_f"], M, out_h2=hid, act=ACT_QUICKGELU, out_scale=HID_SCALE, alpha=inv,
-                      ln_fold=(st2, blk["fc_f"].colsum, 1e-5, Wd))
+                      ln_fold=(mrg, blk["fc_f"].colsum))
             self.gemm(hid, blk["pj"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, alpha=1.0 / HID_SCALE,
-                      row_stats=st1)
+                      row_stats=pcs)
         cls = ws.f32("ccls", Bn, Wd)                                             # class token = row 0 of every image
         hip.gather_rows_h2(xh, inv, Bn, L, Wd, None, 0, cls)
         return cls

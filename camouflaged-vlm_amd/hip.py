@@ -24,6 +24,7 @@ EXPORTS = [
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
+    "cvlm_ln_stats_merge",
 ]
 ABI_VERSION = 5
 
@@ -173,12 +174,13 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          pixel_shuffle: Optional[Tuple[int, int, int]] = None,
          head_major: Optional[Tuple[int, int, int]] = None, out_scale: float = 1.0,
          workspace: Optional[torch.Tensor] = None,
-         ln_fold: Optional[Tuple[torch.Tensor, torch.Tensor, float, int]] = None,
+         ln_fold: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          residual_h2: Optional[Tuple["H2", float]] = None, ldrh: Optional[int] = None,
          row_stats: Optional[torch.Tensor] = None, conv3x3: Optional[Tuple[int, int, int]] = None) -> None:
     """conv3x3 = (H, W, C): `a` is an NHWC image [B*H*W][C] and K = 9*C runs over the taps of a 3x3 / pad 1 convolution
     (implicit GEMM: the im2col gather happens in the DMA addresses).
-    ln_fold = (stats [ceil(D/64)][M][2] f32, colsum [N] f32, eps, D): LayerNorm of the input folded into this GEMM (include/cvlm.h);
+    ln_fold = (merged [M][2] f32 = (rstd, mu * rstd) from ln_stats_merge, colsum [N] f32): LayerNorm of the input folded into this
+    GEMM (include/cvlm.h);
     residual_h2 = (x h2, scale): residual given as h2 planes; row_stats [ceil(N/64)][M][2] f32: piece statistics of the result rows
     (plain stores, bit-reproducible: nothing to zero)."""
     _on_current_device(a.t)
@@ -199,8 +201,8 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
         g.hm_S, g.hm_H, g.hm_hd = head_major
     g.out_scale = out_scale
     if ln_fold is not None:
-        assert tuple(ln_fold[0].shape) == (stats_pieces(ln_fold[3]), M, 2) and ln_fold[0].is_contiguous(), "ln_fold stats: [pieces][M][2]"
-        g.ln_stats, g.ln_colsum, g.ln_eps, g.ln_D = ln_fold[0].data_ptr(), ln_fold[1].data_ptr(), ln_fold[2], ln_fold[3]
+        assert tuple(ln_fold[0].shape) == (M, 2) and ln_fold[0].is_contiguous(), "ln_fold: merged statistics [M][2]"
+        g.ln_stats, g.ln_colsum = ln_fold[0].data_ptr(), ln_fold[1].data_ptr()
     if residual_h2 is not None:
         r, rs = residual_h2
         g.res_hi, g.res_lo, g.ldrh, g.res_scale = r.hi.data_ptr(), r.lo.data_ptr(), (ldrh if ldrh is not None else N), rs
@@ -238,6 +240,17 @@ def add_rows(a: torch.Tensor, b: Optional[torch.Tensor], b_rows: int, M: int, D:
 def stats_pieces(D: int) -> int:
     """Piece planes of a row-statistics buffer for rows of D columns (include/cvlm.h: one (sum, centred squares) pair per 64 columns)."""
     return (D + 63) // 64
+
+
+def ln_stats_merge(pieces: torch.Tensor, M: int, D: int, eps: float, merged: torch.Tensor,
+                   workspace: Optional[torch.Tensor] = None) -> None:
+    """pieces f32 [ceil(D/64)][rows >= M][2] (sum, centred sum of squares per 64 columns) -> merged f32 [M][2] = (rstd, mu * rstd):
+    what `gemm(ln_fold=...)` reads.  workspace: a cvlm_gemm workspace whose error word counts refused rows."""
+    assert pieces.dim() == 3 and pieces.shape[0] == stats_pieces(D) and pieces.shape[1] >= M and pieces.is_contiguous()
+    assert tuple(merged.shape) == (M, 2) and merged.is_contiguous()
+    _check(load().cvlm_ln_stats_merge(C.c_void_p(pieces.data_ptr()), C.c_int64(pieces.shape[1]), C.c_int32(M), C.c_int32(D),
+                                      C.c_float(eps), C.c_void_p(merged.data_ptr()), C.c_void_p(_p(workspace)),
+                                      C.c_void_p(_stream())), "cvlm_ln_stats_merge")
 
 
 def row_stats_split(x: torch.Tensor, scale: float, out: H2, stats: torch.Tensor, M: int, D: int, *, row0: int = 0,

@@ -54,7 +54,7 @@ const char* cvlm_target_arch(void);
  * workspace (fixed summation order); without it every tile is computed whole (same result up to fp32 summation
  * order, slower for 2.5-round shapes).  The first 4 KiB of the workspace are hand-off words: zero them ONCE after
  * allocation (hipMemset); kernels leave them zero.  Word 512 counts abandoned hand-offs (a partner workgroup that
- * never arrived; the affected tile is written as NaN), word 513 rows a LayerNorm-folded launch refused (below): 0 in a
+ * never arrived; the affected tile is written as NaN), word 513 rows cvlm_ln_stats_merge refused (below): 0 in a
  * healthy run.
  */
 typedef struct cvlm_gemm_args {
@@ -75,15 +75,11 @@ typedef struct cvlm_gemm_args {
     int64_t workspace_bytes;     /* ABI 2 */
     /* ABI 3 -- LayerNorm folded into the GEMM that consumes it (image_encoder.py:432,444 + :491 / common.py:25): with
      * W' = W.diag(gamma) packed as the weight, bias' = bias + W.beta and ln_colsum[n] = sum_k W'[n][k],
-     *     out = act( rstd_m * (alpha * acc - mu_m * ln_colsum[n]) + bias'[n] ),   mu = mean of row m,  rstd = 1 / sqrt(var + ln_eps)
-     * of the UN-normalised input (A holds x, possibly scaled: alpha carries the inverse).  ABI 5: the statistics arrive in
-     * PIECES, ln_stats[p][m] = (sum, centred sum of squares) of columns [64p, 64p + 64) of row m, p < ceil(ln_D / 64), piece
-     * planes M rows apart (float [P][M][2]; the layout `row_stats` of the producing launch and cvlm_row_stats_split write).
-     * The consumer merges the pieces of a row in a fixed order (even pieces, odd pieces, then the two), so the result is
-     * bit-reproducible, and as centred moments (no s2 / D - mu^2 cancellation on rows whose mean dwarfs their spread).
-     * Guaranteed range: the fold subtracts mu * colsum from a contraction of the UN-centred row, which costs |mu| / sigma of the
-     * h2 format's 22 bits (measured 4e-6 * |mu| / sigma abs per output); rows with |mu| / sigma > 128 are refused: their
-     * outputs are NaN and, with a workspace, word 513 of its first page counts them (never a finite wrong value).
+     *     out = act( rstd_m * (alpha * acc - mu_m * ln_colsum[n]) + bias'[n] ),   mu = mean of row m,  rstd = 1 / sqrt(var + eps)
+     * of the UN-normalised input (A holds x, possibly scaled: alpha carries the inverse).  ABI 5: ln_stats[m] = (rstd_m,
+     * mu_m * rstd_m), float [M][2], as cvlm_ln_stats_merge writes it from the piece statistics of the producing launch
+     * (`row_stats` below / cvlm_row_stats_split); ln_eps / ln_D are not read by the GEMM any more (they are arguments of the
+     * merge).  Rows the merge refused (|mu| / sigma beyond CVLM_LN_FOLD_MAX_RATIO) carry NaN: every output of such a row is NaN.
      * h2 output only, act in {NONE, GELU, QUICKGELU}, N % 8 == 0. */
     const float* ln_stats; const float* ln_colsum; float ln_eps; int32_t ln_D;
     /* ABI 3 -- the producer side: residual given as h2 planes (value = (hi + lo) * res_scale, leading dimension ldrh) and
@@ -118,9 +114,23 @@ int cvlm_layernorm(const float* x, int64_t ldx, const float* add, int32_t add_ro
 int cvlm_add_rows(const float* a, const float* b, int32_t b_rows, float scale, float* out_f32,
                   void* out_hi, void* out_lo, int32_t M, int32_t D, void* stream);
 
+/* Piece statistics -> the pair per row the LayerNorm-folded cvlm_gemm reads (ABI 5): merged[m] = (rstd_m, mu_m * rstd_m) from
+ * pieces[p][m] = (sum, centred sum of squares) of columns [64p, 64p + 64) of row m, p < ceil(D / 64), piece planes `piece_rows`
+ * rows apart.  The pieces of a row are added in index order, as centred moments (no s2 / D - mu^2 cancellation): the result is
+ * bit-reproducible.  Guaranteed range of the fold: `alpha * acc - mu * colsum` costs |mu| / sigma of the h2 format's 22 bits
+ * (measured 4e-6 * |mu| / sigma abs per output); a row with |mu| / sigma > CVLM_LN_FOLD_MAX_RATIO is refused -- its pair is
+ * NaN and, when `gemm_workspace` (a cvlm_gemm workspace) is given, word CVLM_WS_WORD_LN_REFUSED of its first page counts it:
+ * never a finite wrong value.  A separate launch because the merge inside the consuming GEMM (piece loads between its main loop
+ * and its epilogue) cost that GEMM 7-8 %; this kernel takes ~3 us.  Replaces the statistics half of nn.LayerNorm
+ * (image_encoder.py:432,444; alpha_clip_rw/model.py:315-362). */
+#define CVLM_LN_FOLD_MAX_RATIO 128
+#define CVLM_WS_WORD_LN_REFUSED 513
+int cvlm_ln_stats_merge(const float* pieces, int64_t piece_rows, int32_t M, int32_t D, float eps, float* merged, void* gemm_workspace,
+                        void* stream);
+
 /* Row statistics + split: out h2 = x * scale (both planes), stats[p][m] = (sum, centred sum of squares) of columns
- * [64p, 64p + 64) of the unscaled row m, piece planes `stats_rows` rows apart (the piece layout of cvlm_gemm_args.ln_stats; D % 8 == 0).
- * Seeds the h2 residual stream of the LayerNorm-folded GEMMs (cvlm_gemm_args.ln_stats) from an f32 tensor x [M][D].
+ * [64p, 64p + 64) of the unscaled row m, piece planes `stats_rows` rows apart (the piece layout cvlm_ln_stats_merge reads; D % 8 == 0).
+ * Seeds the h2 residual stream of the LayerNorm-folded GEMMs from an f32 tensor x [M][D].
  * copies > 1 (ABI 4): the same M rows are written `copies` times, copy c at rows c * dst_row_stride of out / stats -- the
  * MaPLe deep visual prompts that replace the last n_ctx tokens of every image before a block
  * (alpha_clip_rw/model.py:392-434) on an h2 stream: out = planes + first_row * D, stats + 2 * first_row, stride = L. */

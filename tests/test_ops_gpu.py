@@ -163,7 +163,9 @@ def test_gemm_split_k_small_grids(hip, monkeypatch, M, N, K, parts):
             o = hip.H2.empty(M, N)
             o.t.fill_(float("nan"))
             st_out = torch.full((hip.stats_pieces(N), M, 2), float("nan"), device="cuda")
-            hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=1, out_h2=o, ln_fold=(st, lin.colsum, 1e-6, K),
+            mrg = torch.empty(M, 2, device="cuda")
+            hip.ln_stats_merge(st, M, K, 1e-6, mrg, ws)
+            hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=1, out_h2=o, ln_fold=(mrg, lin.colsum),
                      workspace=ws)
             o2 = hip.H2(hip.H2.pack(res * XS).t.cuda())
             hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o2, residual_h2=(o2, 1.0 / XS), out_scale=XS, row_stats=st_out, workspace=ws)
@@ -215,8 +217,14 @@ def test_gemm_layernorm_fold_and_h2_residual(hip, M, D, N, act):
     lin = LnLinear(W, b, gamma, beta, dev)
     out = hip.H2.empty(M, N, device=dev)
     out.t.fill_(float("nan"))
+    merged = torch.full((M, 2), float("nan"), device=dev)
+    hip.ln_stats_merge(stats, M, D, 1e-6, merged)
+    mu_ref, var_ref = x_ref.mean(1), x_ref.var(1, unbiased=False)
+    rs_ref = (var_ref + 1e-6).rsqrt()
+    assert float(((merged[:, 0].cpu().double() - rs_ref).abs() / rs_ref).max()) < 5e-6           # v_rsq: 1 ulp
+    assert float(((merged[:, 1].cpu().double() - mu_ref * rs_ref).abs() / (mu_ref.abs() * rs_ref + 1e-3)).max()) < 1e-5
     hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=act, out_h2=out, out_scale=0.25,
-             ln_fold=(stats, lin.colsum, 1e-6, D))
+             ln_fold=(merged, lin.colsum))
     xn = F.layer_norm(got, (D,), gamma.double(), beta.double(), 1e-6)
     z = xn @ W.double().t() + b.double()
     z = {0: z, 1: F.gelu(z), 2: z * torch.sigmoid(1.702 * z)}[act]
@@ -251,7 +259,7 @@ def test_layernorm_fold_common_mode_offset(hip, mean, std):
     LayerNorm at the 1e-3 budget.  The statistics are merged as centred moments, so the VARIANCE does not cancel; what is
     left is `alpha * acc - mu * colsum`, which costs |mu| / sigma of the h2 format's 22 bits.  Guaranteed range
     (include/cvlm.h): |mu| / sigma <= 128 within budget; beyond it the row is refused -- NaN outputs and a count in the
-    workspace, never a finite wrong value."""
+    workspace (cvlm_ln_stats_merge), never a finite wrong value."""
     from camouflaged_vlm_amd.engine import LnLinear
     M, D, N, XS = 600, 1280, 256, 0.25
     dev = "cuda"
@@ -263,7 +271,9 @@ def test_layernorm_fold_common_mode_offset(hip, mean, std):
     lin = LnLinear(W, b, gamma, beta, dev)
     out = hip.H2.empty(M, N, device=dev)
     ws = hip.new_gemm_workspace(dev)
-    hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, out_h2=out, ln_fold=(st, lin.colsum, 1e-6, D), workspace=ws)
+    mrg = torch.empty(M, 2, device=dev)
+    hip.ln_stats_merge(st, M, D, 1e-6, mrg, ws)
+    hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, out_h2=out, ln_fold=(mrg, lin.colsum), workspace=ws)
     got = out.float().cpu().double()
     if abs(mean) / std > 128:
         assert bool(torch.isnan(got).all()) and hip.gemm_workspace_errors(ws) == M
@@ -294,7 +304,7 @@ def test_gemm_persistent_equals_plain(hip, form, monkeypatch):
     W = hip.H2(rn(2, N, K, scale=0.1).half() * torch.tensor([1.0, 2.0 ** -11], device=dev).view(2, 1, 1).half())
     bias = rn(N)
     res, cs = rn(M, N), rn(N)
-    st_in = torch.stack([rn(2, M) * 3.0, 20.0 + rn(2, M).abs() * 5.0], 2).contiguous()       # K = 128: two pieces per row
+    st_in = torch.stack([0.5 + rn(M).abs(), rn(M) * 0.3], 1).contiguous()                     # merged pairs (rstd, mu * rstd)
     x_in = rn(2, M, N).half() * torch.tensor([1.0, 2.0 ** -11], device=dev).view(2, 1, 1).half()
     outs = {}
     for persist in ("0", "1"):
@@ -308,7 +318,7 @@ def test_gemm_persistent_equals_plain(hip, form, monkeypatch):
             o = hip.H2.empty(M, N); o.t.fill_(float("nan")); kw = dict(out_h2=o, head_major=(S, Hh, hd))
         elif form == "ln_fold_gelu":
             o = hip.H2.empty(M, N); o.t.fill_(float("nan"))
-            kw = dict(out_h2=o, act=1, ln_fold=(st_in, cs, 1e-6, K), out_scale=0.25)
+            kw = dict(out_h2=o, act=1, ln_fold=(st_in, cs), out_scale=0.25)
         else:
             xh = hip.H2(x_in.clone())
             o = hip.H2.empty(M, N); o.t.fill_(float("nan"))

@@ -9,6 +9,7 @@ from camouflaged_vlm_amd.engine import Cascade, Precision
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--pipelined", action="store_true", help="the loop bench.py times: stage 2 of a batch fused with the next batch's CLIP pass 1 (one stream here)")
 a = ap.parse_args()
 os.environ["CVLM_OVERLAP_CLIP"] = "0"
 g, c = spec.DEMO_SAM, spec.DEMO_CLIP
@@ -19,7 +20,7 @@ eot = host.eot_for_classes(host.ovcamo_constants()["names_test"].tolist())[:c.n_
 cas.clip.set_text_bank(cas.clip.text_features(eot, "test"), torch.from_numpy(host.ovcamo_constants()["bank_test"]).float(), "test")
 inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=a.batch))
 for _ in range(2):
-    cas.cascade(inp, ci, cm)
+    cas.cascade(inp, ci, cm, pipelined=a.pipelined)
 torch.cuda.synchronize()
 recs = []
 names = ["gemm", "layernorm", "add_rows", "split_f32", "patchify", "im2col3x3", "reinterpret_transpose", "attention",
@@ -57,8 +58,9 @@ for n in names:
 t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 t0.record()
 for _ in range(a.reps):
-    cas.cascade(inp, ci, cm)
+    cas.cascade(inp, ci, cm, pipelined=a.pipelined)
 t1.record()
+cas.flush()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for key, fl, e0, e1 in recs:
