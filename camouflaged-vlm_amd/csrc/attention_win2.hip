@@ -1,0 +1,453 @@
+// ViT-H *window* attention (14x14 windows, head_dim 80, exact mode), producer / consumer form (round 3).
+// image_encoder.py:488-504, 507-553, 589-625; the same mathematics and fragment layouts as attention_win.hip
+// (query on the lane for S^T and O^T, rel-pos bias folded into the QK^T contraction through an augmented k-step pair,
+// pad tokens = qkv bias rows read by source address), a different division of labour:
+//
+//   * ONE workgroup per CU, persistent over a list of (window, head) pairs; 8 waves:
+//       waves 0..6  CONSUMERS, 32 query slots each = 224 >= 196 queries of the pair: K / V tiles are read ONCE per pair
+//                   (attention_win.hip runs two 4-wave workgroups per pair, each streaming all keys);
+//       wave  7     PRODUCER: issues every LDS-DMA instruction of the workgroup -- rel-pos tables and one-hot block once, then
+//                   the K / V tiles of pair after pair as one endless stream of 32-key tiles, two tiles ahead of the consumers.
+//     In attention_win.hip a third of a tile's time goes into ISSUING the five DMA instructions a wave owes per tile (row-offset
+//     reads, 64-bit address arithmetic, m0 set-up, ~125 ns each), and the first tiles of a workgroup land while it waits: here
+//     the consumers issue no vector-memory instruction inside the key loop at all, and the first tiles of pair n + 1 arrive
+//     under the last tiles of pair n (the producer does not know item boundaries, only tile numbers).
+//   * Rings: three K slots, three V slots (10 KB each, both planes).  Step g (global tile number): consumers form the scores of
+//     tile g + 1 and P.V of tile g; the producer, behind the same barrier, requests K(g + 3) and V(g + 2) -- the slots of K(g) and
+//     V(g - 1), last read in step g - 1 -- and waits for everything older (vmcnt = size of the newest batch) before it arrives at
+//     the next barrier, which thereby guarantees K(g + 2), V(g + 1).
+//   * Row offsets of the 224 key slots of a pair are the producer's private LDS table (double-buffered by pair parity).
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "../../include/cvlm.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int OFF>
+__device__ __forceinline__ half4 lds_read_tr16(unsigned lds_addr) {
+    half4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void step_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// one-hot block of K_aug (see attention_win.hip): row = key slot, 32 columns = onehot14(kh) | 0 0 | onehot14(kw) | 0 0,
+// the four 16-byte chunks of a row stored at chunk ^ ((row >> 2) & 3)
+struct OneHotImage2 { half_t v[224 * 32]; };
+constexpr OneHotImage2 make_onehot_image2() {
+    OneHotImage2 im{};
+    for (int s = 0; s < 224; ++s)
+        for (int c = 0; c < 32; ++c) {
+            const int kh = s / 14, kw = s % 14;
+            const bool one = s < 196 && (c == kh || c == 16 + kw);
+            const int chunk = (c >> 3) ^ ((s >> 2) & 3);
+            im.v[s * 32 + chunk * 8 + (c & 7)] = one ? (half_t)1.0f : (half_t)0.0f;
+        }
+    return im;
+}
+__device__ const OneHotImage2 g_onehot2 = make_onehot_image2();
+
+__global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_args g, const int nwx, const int npairs) {
+    constexpr int HD = 80, KS = 5, ND = 3, CPR = 10, KP = 80, VP = 80, L = 14, S_SEQ = 196;
+    constexpr int KT = 32, NKT = 7, NCW = 7;                        // 7 key tiles, 7 consumer waves
+    constexpr int PLANE_B = 5120, SLOT_B = 2 * PLANE_B, IPP = 5;    // 32 rows x 160 B per plane = five 1-KiB DMA pieces
+    constexpr int OFF_K = 0, OFF_V = 3 * SLOT_B, OFF_T = 6 * SLOT_B;
+    constexpr int RT_B = 27 * HD * 2, RS_PIECES = (4 * RT_B + 1023) / 1024, RS_B = RS_PIECES * 1024;   // rel-pos tables: 17 pieces
+    constexpr int OFF_OH = OFF_T + RS_B, OH_B = 224 * 32 * 2;
+    constexpr int OFF_TOK = OFF_OH + OH_B, TOK_B = 2 * 224 * 8;     // per pair parity: [K | V][224] row offsets
+    constexpr int TP = 17, OFF_TAUG = OFF_TOK + 2 * TOK_B;          // [224 queries][14 values, 2 zeros, 1 dump slot]
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qc = lane & 31, half = lane >> 5;
+    const int D = g.heads * HD;
+    const half_t* qkv_hi = (const half_t*)g.qkv_hi;
+    const half_t* qkv_lo = (const half_t*)g.qkv_lo;
+    const half_t* pad_hi = (const half_t*)g.pad_hi;
+    const half_t* pad_lo = (const half_t*)g.pad_lo;
+    const int64_t qkv_plane = qkv_lo - qkv_hi, pad_plane = pad_lo - pad_hi;   // lo-plane displacement (elements)
+    const int nwin = nwx * nwx;
+    const int SI = g.grid * g.grid;
+    const QkvStrides QS = qkv_strides(g.qkv_layout, SI, g.B, g.heads, HD);
+    // this workgroup's pairs: blockIdx.x, + gridDim.x, ...; T = its number of key tiles
+    const int my_items = blockIdx.x < npairs ? (npairs - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int T = my_items * NKT;
+    auto pair_of = [&](int k) -> int { return (int)blockIdx.x + k * (int)gridDim.x; };
+    auto token_of = [&](int pair, int slot) -> int {
+        const int seq = pair / g.heads;
+        const int w = seq % nwin;
+        const int wy = w / nwx, wx = w - wy * nwx;
+        const int iy = slot / L, ix = slot - iy * L;
+        const int y = wy * L + iy, x = wx * L + ix;
+        if (y >= g.grid || x >= g.grid) return -1;
+        return y * g.grid + x;
+    };
+
+    if (wave == NCW) {
+        // ================================================= PRODUCER =================================================
+        long long* tokoff = (long long*)(smem + OFF_TOK);
+        auto fill_tokoff = [&](int k) {                              // row offsets of pair k's 224 key slots -> buffer k & 1
+            const int pair = pair_of(k);
+            const int head = pair % g.heads, b = (pair / g.heads) / nwin;
+            long long* tk = tokoff + (k & 1) * (TOK_B / 8);
+            const long long pad_delta = pad_hi - qkv_hi;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sl = lane + 64 * r;
+                if (sl < 224) {
+                    const int tok = token_of(pair, sl < S_SEQ ? sl : S_SEQ - 1);
+                    const long long ko = tok < 0 ? pad_delta + D + head * HD : (long long)qkv_offset(QS, b, tok, 1, head);
+                    tk[sl] = ko | (tok < 0 ? 1 : 0);
+                    tk[224 + sl] = (ko + (tok < 0 ? (long long)D : (long long)QS.sop)) | (tok < 0 ? 1 : 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private table: LDS keeps this wave's accesses in order
+        };
+        int row_s[IPP], ch_s[IPP];                                    // this lane's row / 16-byte chunk in piece `sub` of a plane image
+#pragma unroll
+        for (int sub = 0; sub < IPP; ++sub) {
+            const int c = sub * 64 + lane;
+            row_s[sub] = c / CPR;
+            ch_s[sub] = c - row_s[sub] * CPR;
+        }
+        auto issue_tile = [&](int op, int gt) {                       // key tile gt of the stream (pair gt / 7, tile gt % 7) of K (0) or V (1)
+            const int k = gt / NKT, t = gt - k * NKT;
+            const long long* tk = tokoff + (k & 1) * (TOK_B / 8) + op * 224 + t * KT;
+            unsigned char* dst = smem + (op ? OFF_V : OFF_K) + (gt % 3) * SLOT_B;
+            const half_t* src[IPP][2];
+#pragma unroll
+            for (int sub = 0; sub < IPP; ++sub) {
+                const long long ko = tk[row_s[sub]];
+                const long long disp = (ko & 1) ? pad_plane : qkv_plane;
+                src[sub][0] = qkv_hi + ((ko & ~7ll) + ch_s[sub] * 8);
+                src[sub][1] = src[sub][0] + disp;
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int sub = 0; sub < IPP; ++sub) glds16(src[sub][pl], dst + pl * PLANE_B + sub * 1024);
+        };
+        // once: rel-pos tables (4 planes back to back, 17 pieces) and the one-hot block (14 pieces)
+        {
+            const unsigned char* t0 = (const unsigned char*)g.relh_hi;
+            const unsigned char* t1 = (const unsigned char*)g.relh_lo;
+            const unsigned char* t2 = (const unsigned char*)g.relw_hi;
+            const unsigned char* t3 = (const unsigned char*)g.relw_lo;
+#pragma unroll 1
+            for (int i = 0; i < RS_PIECES; ++i) {
+                int byte = i * 1024 + lane * 16;
+                if (byte >= 4 * RT_B) byte = 0;                       // tail of the last piece: lands in the slack behind the image
+                const int tbl = byte / RT_B, off = byte - tbl * RT_B;
+                const unsigned char* src = (tbl == 0 ? t0 : (tbl == 1 ? t1 : (tbl == 2 ? t2 : t3))) + off;
+                glds16(src, smem + OFF_T + i * 1024);
+            }
+            const unsigned char* oh = (const unsigned char*)g_onehot2.v;
+#pragma unroll 1
+            for (int i = 0; i < OH_B / 1024; ++i) glds16(oh + i * 1024 + lane * 16, smem + OFF_OH + i * 1024);
+        }
+        if (T > 0) {
+            fill_tokoff(0);
+            issue_tile(0, 0);
+            if (T > 1) issue_tile(0, 1);
+            if (T > 2) issue_tile(0, 2);
+            issue_tile(1, 0);
+            if (T > 1) issue_tile(1, 1);
+        }
+        wait_vm<0>();
+        step_barrier();                                               // B_start: tables, one-hot block, K(0..2), V(0..1) are in LDS
+#pragma unroll 1
+        for (int gt = 0; gt < T; ++gt) {
+            step_barrier();                                           // B_gt: every consumer has left step gt - 1
+            const int kn = gt + 3, vn = gt + 2;
+            if (kn < T && kn % NKT == 0) fill_tokoff(kn / NKT);       // the stream enters a new pair with its first K tile
+#if defined(CVLM_WIN2_PROBE) && CVLM_WIN2_PROBE == 2
+            const bool ik = false, iv = false;                        // probe: no DMA in the loop (consumers read stale tiles)
+#else
+            const bool ik = kn < T, iv = vn < T;
+#endif
+            if (ik) issue_tile(0, kn);
+            if (iv) issue_tile(1, vn);
+            // everything but the batch just issued has landed -> K(gt + 2), V(gt + 1) are there when we arrive at B_(gt+1)
+            if (ik && iv) wait_vm<4 * IPP>();
+            else if (ik || iv) wait_vm<2 * IPP>();
+            else wait_vm<0>();
+        }
+        return;
+    }
+
+    // ===================================================== CONSUMERS =====================================================
+    float* Taug = (float*)(smem + OFF_TAUG);
+    const half_t* OH = (const half_t*)(smem + OFF_OH);
+    auto k_slot = [&](int gt) -> const unsigned char* { return smem + OFF_K + (gt % 3) * SLOT_B; };
+    auto v_slot = [&](int gt) -> const unsigned char* { return smem + OFF_V + (gt % 3) * SLOT_B; };
+    const int tg = lane >> 4, ti = lane & 15;
+    const int v_lane_off = (4 * (tg >> 1) + (ti >> 2)) * VP + 16 * (tg & 1) + 4 * (ti & 3);
+    typedef std::integral_constant<bool, false> no_c;
+    typedef std::integral_constant<bool, true> yes_c;
+    bool first = true;
+
+#pragma unroll 1
+    for (int k = 0; k < my_items; ++k) {
+        const int pair = pair_of(k);
+        const int head = pair % g.heads, b = (pair / g.heads) / nwin;
+        const int gt0 = k * NKT;
+        // ---- queries
+        const int qslot = wave * 32 + qc;
+        const bool qvalid = qslot < S_SEQ;
+        const int qs = qvalid ? qslot : S_SEQ - 1;
+        const int qtok = token_of(pair, qs);
+        half8 qh[KS + 2], ql[KS + 2];
+        {
+            const int64_t qo = qtok < 0 ? (int64_t)head * HD : qkv_offset(QS, b, qtok, 0, head);
+            const half_t* bh = (qtok < 0 ? pad_hi : qkv_hi) + qo;
+            const half_t* bl = bh + (qtok < 0 ? pad_plane : qkv_plane);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                qh[ks] = *(const half8*)(bh + 16 * ks + 8 * half);
+                ql[ks] = *(const half8*)(bl + 16 * ks + 8 * half);
+            }
+        }
+        if (first) { step_barrier(); first = false; }                // B_start (once): tables and one-hot block are in LDS
+        // ---- Th / Tw for this query: U = Q . R^T (27 rows -> one 32-row MFMA tile per table), scattered through Taug
+        {
+            const int qhh = qs / L, qww = qs - qhh * L;
+            float* Tq = Taug + (wave * 32 + qc) * TP;
+            if (half == 0) { Tq[14] = 0.f; Tq[15] = 0.f; }
+            const int rr = qc < 27 ? qc : 26;
+            floatx16 u[2];
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const unsigned char* rt = smem + OFF_T + (2 * tb) * RT_B + rr * (HD * 2) + 16 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u[tb][r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const half8 rh = *(const half8*)(rt + 32 * ks);
+                    const half8 rl = *(const half8*)(rt + RT_B + 32 * ks);
+                    u[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, qh[ks], u[tb], 0, 0, 0);
+                    u[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rl, qh[ks], u[tb], 0, 0, 0);
+                    u[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, ql[ks], u[tb], 0, 0, 0);
+                }
+            }
+            // the scores use q * scale (image_encoder.py:496), the rel-pos tables q itself (:497-500)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    half_t hh, ll;
+                    split_h2(((float)qh[ks][j] + (float)ql[ks][j]) * g.scale, hh, ll);
+                    qh[ks][j] = hh;
+                    ql[ks][j] = ll;
+                }
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                int cq = tb ? qww : qhh;
+                asm volatile("" : "+v"(cq), "+v"(u[tb][0]));          // keep the scatter's index arithmetic behind the MFMAs (register pressure)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                        // branch-free scatter: rows that do not exist land in the dump slot
+                    const int j = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int kidx = cq + L - 1 - j;
+                    const bool ok = j < 27 && kidx >= 0 && kidx < L;
+                    Tq[ok ? kidx : 16] = u[tb][r];
+                }
+                __builtin_amdgcn_wave_barrier();                      // rows are wave-private: LDS keeps a wave's accesses in order
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    half_t h, l;
+                    split_h2(Tq[8 * half + j], h, l);
+                    qh[KS + tb][j] = h;
+                    ql[KS + tb][j] = l;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
+        float m_run = -INFINITY, l_run = 0.f;
+        floatx16 o[ND];
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+
+        // S^T tile of key tile t of this pair (stream tile gt0 + t): 15 + 4 (bias) MFMAs
+        auto scores = [&](int t, auto last_c) -> floatx16 {
+            floatx16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const half_t* kr = (const half_t*)k_slot(gt0 + t) + qc * KP + 8 * half;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 kh = *(const half8*)(kr + 16 * ks);
+                const half8 kl = *(const half8*)(kr + PLANE_B / 2 + 16 * ks);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+            }
+            const int row = t * KT + qc;
+            const half_t* ohr = OH + row * 32;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {                             // bias: exact one-hot rows x (T/scale) hi + lo
+                const half8 oh8 = *(const half8*)(ohr + 8 * ((half + 2 * a) ^ ((row >> 2) & 3)));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, qh[KS + a], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(oh8, ql[KS + a], s, 0, 0, 0);
+            }
+            if (decltype(last_c)::value) {                            // only the last tile holds slots beyond the 196 keys
+                const int b0 = t * KT + 4 * half;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (b0 + (r & 3) + 8 * (r >> 2) >= S_SEQ) s[r] = -INFINITY;
+            }
+            return s;
+        };
+        // K(gt0) is in LDS: B_(gt0 - 1) of the previous pair (or B_start) guaranteed it, and its slot is not written again before
+        // the batch behind B_(gt0)
+        floatx16 s_cur = scores(0, no_c{});
+
+        auto tile = [&](int t, auto has_next_c, auto next_last_c) {
+            constexpr bool HAS_NEXT = decltype(has_next_c)::value;
+            step_barrier();                                           // B_(gt0 + t): K(gt0 + t + 1) and V(gt0 + t) have landed
+#if defined(CVLM_WIN2_PROBE) && CVLM_WIN2_PROBE == 1
+            return;                                                   // probe: consumers only keep step with the producer
+#endif
+            floatx16 s_next;
+            if (HAS_NEXT) s_next = scores(t + 1, next_last_c);
+            const unsigned vaddr = (unsigned)(size_t)(LDS_AS const unsigned char*)v_slot(gt0 + t) + 2u * (unsigned)v_lane_off;
+            auto read_v = [&](auto k2_c, half4 (&v0)[ND][2], half4 (&v1)[ND][2]) {
+                constexpr int K2 = decltype(k2_c)::value;
+                v0[0][0] = lds_read_tr16<2 * (16 * K2 * VP + 0)>(vaddr);       v1[0][0] = lds_read_tr16<2 * (16 * K2 * VP + 0 + 8 * VP)>(vaddr);
+                v0[1][0] = lds_read_tr16<2 * (16 * K2 * VP + 32)>(vaddr);      v1[1][0] = lds_read_tr16<2 * (16 * K2 * VP + 32 + 8 * VP)>(vaddr);
+                v0[2][0] = lds_read_tr16<2 * (16 * K2 * VP + 64)>(vaddr);      v1[2][0] = lds_read_tr16<2 * (16 * K2 * VP + 64 + 8 * VP)>(vaddr);
+                v0[0][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 0)>(vaddr);  v1[0][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 0 + 8 * VP)>(vaddr);
+                v0[1][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 32)>(vaddr); v1[1][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 32 + 8 * VP)>(vaddr);
+                v0[2][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 64)>(vaddr); v1[2][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 64 + 8 * VP)>(vaddr);
+            };
+            half4 va0[ND][2], va1[ND][2], vb0[ND][2], vb1[ND][2];
+            read_v(std::integral_constant<int, 0>{}, va0, va1);         // in flight under the softmax
+            const floatx16 s = s_cur;
+            float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+            mx = half_swap_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            const f32x2 c2 = f32x2{-m_new * LOG2E, -m_new * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
+            f32x2 z[8], acc = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 a = f32x2{s[2 * i], s[2 * i + 1]} * l2 + c2;
+                z[i] = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                acc += z[i];
+            }
+            l_run = l_run * alpha + (acc.x + acc.y);
+#pragma unroll
+            for (int n = 0; n < ND; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+            m_run = m_new;
+            half8 ph[2], pl[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {                      // hi truncated (cvt_pkrtz), lo = e - hi: exact remainder
+                    const f32x2 e = z[4 * k2 + p2];
+                    const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x, e.y));
+                    const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x - (float)h[0], e.y - (float)h[1]));
+                    ph[k2][2 * p2] = h[0]; ph[k2][2 * p2 + 1] = h[1];
+                    pl[k2][2 * p2] = l[0]; pl[k2][2 * p2 + 1] = l[1];
+                }
+            auto pv = [&](int k2, half4 (&v0)[ND][2], half4 (&v1)[ND][2]) {
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    const half8 vh = half8{v0[n][0][0], v0[n][0][1], v0[n][0][2], v0[n][0][3], v1[n][0][0], v1[n][0][1], v1[n][0][2], v1[n][0][3]};
+                    const half8 vl = half8{v0[n][1][0], v0[n][1][1], v0[n][1][2], v0[n][1][3], v1[n][1][0], v1[n][1][1], v1[n][1][2], v1[n][1][3]};
+                    o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[k2], o[n], 0, 0, 0);
+                    o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[k2], o[n], 0, 0, 0);
+                    o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[k2], o[n], 0, 0, 0);
+                }
+            };
+            lds_wait();                                               // step-0 fragments (and everything older) are in registers
+            read_v(std::integral_constant<int, 1>{}, vb0, vb1);         // in flight under the first nine MFMAs
+            pv(0, va0, va1);
+            lds_wait();
+            pv(1, vb0, vb1);
+            if (HAS_NEXT) s_cur = s_next;
+        };
+#pragma unroll 1
+        for (int t = 0; t < NKT - 2; ++t) tile(t, yes_c{}, no_c{});
+        tile(NKT - 2, yes_c{}, yes_c{});
+        tile(NKT - 1, no_c{}, no_c{});
+
+        // ---- output: 16-byte stores (v_permlane32_swap pairs, see attention_win.hip)
+        const float l_tot = half_swap_sum(l_run);
+        const float inv = 1.0f / l_tot;
+        const bool st_ok = qvalid && qtok >= 0;
+        const int64_t orow = ((int64_t)b * SI + (st_ok ? qtok : 0)) * D + head * HD;
+        half_t* oh = (half_t*)g.out_hi + orow;
+        half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
+#pragma unroll
+        for (int n = 0; n < ND; ++n)
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                if (32 * n + 16 * rp < HD) {                          // compile-time
+                    unsigned xe[2][2], xo[2][2];                      // [plane][dword] of the even / odd 8-dim group
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        half_t h[4], l4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) split_h2(o[n][4 * (2 * rp + e) + j] * inv, h[j], l4[j]);
+                        unsigned (&x)[2][2] = e ? xo : xe;
+                        x[0][0] = __builtin_bit_cast(unsigned, half2v{h[0], h[1]});
+                        x[0][1] = __builtin_bit_cast(unsigned, half2v{h[2], h[3]});
+                        x[1][0] = __builtin_bit_cast(unsigned, half2v{l4[0], l4[1]});
+                        x[1][1] = __builtin_bit_cast(unsigned, half2v{l4[2], l4[3]});
+                    }
+                    const int d = 32 * n + 16 * rp + 8 * half;       // lower lanes: the even group, upper lanes: the odd group
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(xe[pl][0], xo[pl][0], false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(xe[pl][1], xo[pl][1], false, false);
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 v = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                        half_t* dst = pl ? ol : oh;
+                        if (st_ok && dst) *(u32x4*)(dst + d) = v;
+                    }
+                }
+            }
+    }
+    if (first) step_barrier();                                        // a workgroup without pairs still meets the producer at B_start
+}
+
+}  // namespace
+
+// exact-mode (split 3/3) producer / consumer form; called from cvlm_attention_window14() when selected
+int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s) {
+    constexpr int smem = 6 * 10240 + 17 * 1024 + 224 * 32 * 2 + 2 * (2 * 224 * 8) + 224 * 17 * 4;
+    const int nwx = (g.grid + 13) / 14;
+    const int npairs = g.heads * g.B * nwx * nwx;
+    static bool attr[16] = {};
+    if (cvlm_first_on_device(attr))
+        (void)hipFuncSetAttribute((const void*)attn_win14p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static int cus_[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& cus = cus_[dev & 15];
+    if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int wgs = npairs < cus ? npairs : cus;
+    hipLaunchKernelGGL(attn_win14p_kernel, dim3(wgs), dim3(512), smem, s, g, nwx, npairs);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
