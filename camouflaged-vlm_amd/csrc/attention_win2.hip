@@ -199,28 +199,36 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
     typedef std::integral_constant<bool, false> no_c;
     typedef std::integral_constant<bool, true> yes_c;
     bool first = true;
+    const int qslot = wave * 32 + qc;
+    const bool qvalid = qslot < S_SEQ;
+    const int qs = qvalid ? qslot : S_SEQ - 1;
+    // The query rows of the NEXT pair are requested at the top of a pair's last key tile: from there on the augmented query
+    // fragments are dead (the last scores were formed one tile earlier), so the 40 registers are free, and the loads' latency
+    // (~1.5 us of a ~20-us pair when asked for at the top of the pair) passes under that tile and the output stage.
+    half8 qn_h[KS], qn_l[KS];
+    auto load_q = [&](int pair) {
+        const int head = pair % g.heads, b = (pair / g.heads) / nwin;
+        const int qtok = token_of(pair, qs);
+        const int64_t qo = qtok < 0 ? (int64_t)head * HD : qkv_offset(QS, b, qtok, 0, head);
+        const half_t* bh = (qtok < 0 ? pad_hi : qkv_hi) + qo;
+        const half_t* bl = bh + (qtok < 0 ? pad_plane : qkv_plane);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qn_h[ks] = *(const half8*)(bh + 16 * ks + 8 * half);
+            qn_l[ks] = *(const half8*)(bl + 16 * ks + 8 * half);
+        }
+    };
+    if (my_items > 0) load_q(pair_of(0));
 
 #pragma unroll 1
     for (int k = 0; k < my_items; ++k) {
         const int pair = pair_of(k);
         const int head = pair % g.heads, b = (pair / g.heads) / nwin;
         const int gt0 = k * NKT;
-        // ---- queries
-        const int qslot = wave * 32 + qc;
-        const bool qvalid = qslot < S_SEQ;
-        const int qs = qvalid ? qslot : S_SEQ - 1;
         const int qtok = token_of(pair, qs);
         half8 qh[KS + 2], ql[KS + 2];
-        {
-            const int64_t qo = qtok < 0 ? (int64_t)head * HD : qkv_offset(QS, b, qtok, 0, head);
-            const half_t* bh = (qtok < 0 ? pad_hi : qkv_hi) + qo;
-            const half_t* bl = bh + (qtok < 0 ? pad_plane : qkv_plane);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                qh[ks] = *(const half8*)(bh + 16 * ks + 8 * half);
-                ql[ks] = *(const half8*)(bl + 16 * ks + 8 * half);
-            }
-        }
+        for (int ks = 0; ks < KS; ++ks) { qh[ks] = qn_h[ks]; ql[ks] = qn_l[ks]; }
         if (first) { step_barrier(); first = false; }                // B_start (once): tables and one-hot block are in LDS
         // ---- Th / Tw for this query: U = Q . R^T (27 rows -> one 32-row MFMA tile per table), scattered through Taug
         {
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 #pragma unroll 1
         for (int t = 0; t < NKT - 2; ++t) tile(t, yes_c{}, no_c{});
         tile(NKT - 2, yes_c{}, yes_c{});
+        if (k + 1 < my_items) load_q(pair_of(k + 1));
         tile(NKT - 1, no_c{}, no_c{});
 
         // ---- output: 16-byte stores (v_permlane32_swap pairs, see attention_win.hip)
