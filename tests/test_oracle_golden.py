@@ -115,3 +115,44 @@ def test_oracle_matches_reference_on_outlier_weights(golden_dir):
     assert float((m - torch.from_numpy(go["mask_logits"])).abs().max()) < 1e-4
     assert float((l - torch.from_numpy(go["class_logits"])).abs().max()) < 1e-4
     assert p.tolist() == go["pred"].tolist()
+
+
+def test_digest_checker_accepts_the_reference_and_rejects_deviations(golden_dir):
+    """camouflaged_vlm_amd.digest (the gate bench.py and the GPU tests share) on synthetic outputs built FROM the digest: a mask
+    with the reference's sign bits and sampled logits passes for every image; a flipped region, a logit off by 2e-3, a wrong
+    prediction each fail; image ids the digest does not hold are skipped, not passed silently as 'checked'."""
+    import torch
+    from camouflaged_vlm_amd import digest
+    dg = digest.load(os.path.join(golden_dir, "demo_digest.npz"))
+    n = digest.n_images(dg)
+    assert n == 16 and dg["mask_bits"].shape == (16, 131072) and dg["feat_samples"].shape == (16, 16384)
+    ids = [0, 5, 15]
+    S = 1024
+
+    def outputs():
+        masks = []
+        for i in ids:
+            m = np.where(np.unpackbits(dg["mask_bits"][i])[:S * S].astype(bool), 1.0, -1.0).astype(np.float32)
+            m[dg["sample_idx"]] = dg["mask_samples"][i]
+            masks.append(m.reshape(1, S, S))
+        return (torch.from_numpy(np.stack(masks)), torch.from_numpy(dg["pred"][ids].copy()),
+                torch.from_numpy(dg["class_logits"][ids].copy()))
+
+    m, p, l = outputs()
+    r = digest.check_cascade(m, p, l, dg, ids)
+    assert r["ok"] and r["checked_images"] == ids and r["min_iou"] == 1.0 and r["max_abs_mask_err"] == 0.0
+    m2 = m.clone()
+    m2[1, 0, :64, :64] *= -1.0                                       # flip a 64 x 64 patch of image 5
+    assert not digest.check_cascade(m2, p, l, dg, ids)["ok"]
+    l2 = l.clone()
+    l2[2, 7] += 2e-3
+    assert not digest.check_cascade(m, p, l2, dg, ids)["ok"]
+    p2 = p.clone()
+    p2[0] = (p2[0] + 1) % 61
+    assert not digest.check_cascade(m, p2, l, dg, ids)["ok"]
+    r = digest.check_cascade(m, p, l, dg, [0, 16, 99])               # only image 0 exists in the digest
+    assert r["checked_images"] == [0]
+    assert digest.check_cascade(m[:1], p[:1], l[:1], dg, [40])["checked_images"] == []
+    # encoder features: NHWC tokens rebuilt from nothing but the samples cannot pass the channel-mean gate
+    f = torch.zeros(64 * 64, 256)
+    assert not digest.check_demo_features(f, 64, dg, [0])["ok"]
