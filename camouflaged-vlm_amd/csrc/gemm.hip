@@ -409,39 +409,40 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         constexpr bool PRIO = (DBG == 7);                              // probe: s_setprio around the MFMA groups
         if (DBG == 8 && grpB) __builtin_amdgcn_s_setprio(1);          // probe: static priority for the younger half
         const int co = chunk_off(0);
-        half8 wh[4], wl[4], ah[4], al[4];
-        auto mfma_half = [&](int mh, int tn, int sn) {           // 4 m-tiles; optional DMA of tile tn into slot sn
+        static_assert(NSTAGE != 5 || (MT % 2) == 0, "staggered loop: the m-tiles of a wave split into two halves");
+        constexpr int MH = MT / 2;                                     // m-tiles per phase (4 for the 256-row tile, 3 for the 192-row one)
+        half8 wh[4], wl[4], ah[MH > 0 ? MH : 1], al[MH > 0 ? MH : 1];
+        auto mfma_half = [&](int mh, int tn, int sn) {           // MH m-tiles; optional DMA of tile tn into slot sn
             const bool dma = tn >= 0 && tn < nk && DBG != 1;
             const int64_t koff = (int64_t)tn * BK;
             unsigned char* nxt = smem + sn * STAGE;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MH; ++mt) {
                 if (DBG != 2) {
                     if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        floatx4 c = acc[mh * 4 + mt][nt];
+                        floatx4 c = acc[mh * MH + mt][nt];
                         if (SPLIT == 3) {
                             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], c, 0, 0, 0);
                         }
-                        acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
+                        acc[mh * MH + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
                     }
                     if (PRIO) __builtin_amdgcn_s_setprio(0);
                 }
-                if (dma) {
-                    constexpr int PP = PER_WAVE / 4;
+                if (dma) {                                        // this wave's DMA pieces, spread over the MFMA groups of the phase
 #pragma unroll
-                    for (int j = mt * PP; j < (mt == 3 ? PER_WAVE : (mt + 1) * PP); ++j)
+                    for (int j = (mt * PER_WAVE) / MH; j < ((mt + 1) * PER_WAVE) / MH; ++j)
                         glds16(src[j] + koff, nxt + dst_off[j]);
                 }
             }
         };
         auto read_a = [&](const unsigned char* cur, int mh) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = *(const half8*)(cur + a_row + (mh * 4 + i) * 16 * ROWB + co);
-                if (SPLIT == 3) al[i] = *(const half8*)(cur + A_PLANE + a_row + (mh * 4 + i) * 16 * ROWB + co);
+            for (int i = 0; i < MH; ++i) {
+                ah[i] = *(const half8*)(cur + a_row + (mh * MH + i) * 16 * ROWB + co);
+                if (SPLIT == 3) al[i] = *(const half8*)(cur + A_PLANE + a_row + (mh * MH + i) * 16 * ROWB + co);
             }
         };
         auto read_w = [&](const unsigned char* cur) {
@@ -875,7 +876,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                         }
                     }
                 }
-                if (MODE == 2 && (mt & 3) == 3 && g.row_stats && n0 < g.N) {
+                if (MODE == 2 && ((mt & 3) == 3 || mt == MT - 1) && g.row_stats && n0 < g.N) {
                     // The 64 row pieces of four slabs go out as ONE 512-byte store with all lanes active: lane (r, q) writes row
                     // piece q of row group r into this wave's piece plane, row_stats[piece][m] (plain stores: the consumer adds
                     // the pieces of a row in a fixed order, so the statistics are bit-reproducible and need no zeroing).
@@ -883,8 +884,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     float a1 = ps1[0], a2 = ps2[0];
 #pragma unroll
                     for (int k = 1; k < 8; ++k) { a1 = (q == k) ? ps1[k] : a1; a2 = (q == k) ? ps2[k] : a2; }
-                    const int m = mw + (mt - 3 + (q >> 1)) * 16 + rowh + 8 * (q & 1);
-                    if (m < m_lim) *(float2*)(g.row_stats + 2 * ((int64_t)(n0 >> 6) * g.M + m)) = make_float2(a1, a2);
+                    // a group is four slabs, or what is left of the wave's m-tiles (192-row tile: 4 + 2)
+                    const int m = mw + (mt - (mt & 3) + (q >> 1)) * 16 + rowh + 8 * (q & 1);
+                    if ((q >> 1) <= (mt & 3) && m < m_lim)
+                        *(float2*)(g.row_stats + 2 * ((int64_t)(n0 >> 6) * g.M + m)) = make_float2(a1, a2);
                 }
                 if (NBUF == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab fully read before it is overwritten
                 // PERSIST: the next tile's K-tiles 0 / 1 (requested before this epilogue) have had two slabs' time to land; the
@@ -1271,6 +1274,25 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         const bool lds_staged = ga.ps_c2 == 0 && (ga.N & 7) == 0 && (ga.hm_S == 0 || ((ga.hm_hd & 7) == 0 && ga.hm_S >= 128)) &&
                                 (ga.ldo & 3) == 0 && (ga.stride_o & 3) == 0 && (ga.ldr & 3) == 0 && (ga.stride_r & 3) == 0 &&
                                 (ga.ldoh & 7) == 0 && (ga.stride_oh & 7) == 0;
+        // 192 x 256 tiles (MT = 6, same staggered loop) for grids UNDER one round of 256^2 tiles: the CLIP out_proj / c_proj of the
+        // fused 16-image forward are 37 x 4 = 148 tiles on 256 CUs; 49 x 4 = 196 tiles of 192 rows put 48 more CUs to work and
+        // every workgroup finishes a quarter earlier.  Only the h2-residual form is instantiated (what those launches use).
+        static int t192_env = env_int("CVLM_GEMM_T192", 1);
+        if (live_env) t192_env = env_int("CVLM_GEMM_T192", 1);
+        if (variant == 7 && variant_env == 0 && t192_env && h2res && lds_staged && p.a.batch == 1 && p.tail_rem == 0 && g.M > 4096) {
+            const long t5 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256), t6 = (long)((g.M + 191) / 192) * ((g.N + 255) / 256);
+            if (t5 <= 256 && t6 <= 256 && t6 > t5) {
+                constexpr int smem6 = 2 * 2 * (192 + 256) * 32 * 2;
+                p.nbx = (g.N + 255) / 256; p.nby = (g.M + 191) / 192;
+                auto k6 = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 6, false, 2>;
+                static bool attr6[16] = {};
+                if (cvlm_first_on_device(attr6))
+                    (void)hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, smem6);
+                hipLaunchKernelGGL(k6, dim3(p.nbx * p.nby, 1), dim3(512), smem6, s, p);
+                CVLM_CHECK_LAUNCH();
+                return 0;
+            }
+        }
         if (variant == 7 && persist_env && (variant_env == 0 || variant_env == 7) && lds_staged && p.a.batch == 1) {
             static int cus_[16] = {};
             int dev = 0;

@@ -335,6 +335,34 @@ def test_gemm_persistent_equals_plain(hip, form, monkeypatch):
         assert torch.equal(outs["0"][1], outs["1"][1]) and bool(torch.isfinite(outs["0"][1]).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(9296, 1024, 256), (9296 - 100, 1024, 4096), (6000, 768, 128)])
+def test_gemm_192_row_tiles_equal_256_row_tiles(hip, monkeypatch, M, N, K):
+    """Grids under one round of 256^2 tiles (CLIP out_proj / c_proj of the fused 16-image forward) run on 192 x 256 tiles
+    (CVLM_GEMM_T192, h2-residual form): same K order, so outputs and piece statistics are bit-identical to the 256-row tiling,
+    ragged last row tile included."""
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(11)
+    rn = lambda *sh, scale=1.0: torch.randn(*sh, device=dev, generator=g) * scale
+    planes = torch.tensor([1.0, 2.0 ** -11], device=dev).view(2, 1, 1).half()
+    A = hip.H2(rn(2, M, K).half() * planes)
+    W = hip.H2(rn(2, N, K, scale=0.1).half() * planes)
+    x0 = rn(2, M, N).half() * planes
+    bias = rn(N)
+    ws = hip.new_gemm_workspace(dev)
+    got = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CVLM_GEMM_T192", flag)
+        x = hip.H2(x0.clone())
+        st = torch.full((hip.stats_pieces(N), M, 2), float("nan"), device=dev)
+        hip.gemm(A, W, M, N, K, bias=bias, out_h2=x, residual_h2=(x, 4.0), out_scale=0.25, row_stats=st, workspace=ws)
+        torch.cuda.synchronize()
+        got[flag] = (x.t.clone(), st)
+    assert bool(torch.isfinite(got["1"][0].float()).all()) and bool(torch.isfinite(got["1"][1]).all())
+    assert torch.equal(got["0"][0], got["1"][0]) and torch.equal(got["0"][1], got["1"][1])
+    ref = (A.float().double() @ W.float().double().t() + bias.double() + hip.H2(x0).float().double() * 4.0)
+    assert float((got["1"][0].float().sum(0).double() / 0.25 - ref).abs().max() / ref.abs().max()) < 3e-6
+
+
 @pytest.mark.parametrize("Bn,H,W,Cc,N", [(2, 20, 24, 32, 64), (1, 64, 64, 256, 256), (3, 9, 7, 64, 32)])
 def test_gemm_implicit_conv3x3(hip, Bn, H, W, Cc, N):
     """conv3x3 = (H, W, C) on the NHWC image == cvlm_im2col3x3 + plain GEMM (same K order: bit-identical), and both match
