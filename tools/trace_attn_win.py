@@ -2,6 +2,7 @@
   make -C camouflaged-vlm_amd/csrc EXTRA=-DCVLM_PROBES LIBDIR=../lib_probe
   CVLM_PROBE_LIB=camouflaged-vlm_amd/lib_probe/libcvlm_hip.so python tools/trace_attn_win.py"""
 import ctypes as C, os, sys
+os.environ["CVLM_ATTN_WIN"] = "1"      # the timeline stamps live in the round-2 form of the kernel (attention_win.hip)
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from camouflaged_vlm_amd import hip
@@ -24,8 +25,9 @@ t = buf.cpu().numpy()[:nwg * 8].reshape(nwg, 8)
 x = buf.cpu().numpy()[nwg * 8:].reshape(nwg, 8)
 us = lambda x: x / 100.0
 print(f"{nwg} workgroups, span {us(t[:, 3].max() - t[:, 0].min()):.1f} us")
+halfbit = (np.arange(nwg) >> 3) & 1    # 1-D grid (round 3): workgroups id and id + 8 are the two query halves of a pair
 for half, lab in ((0, "128-query workgroups"), (1, "68-query workgroups")):
-    tt = t[half::2]
+    tt = t[halfbit == half]
     for name, v in (("  loads+offsets+dma issue", us(tt[:, 4] - tt[:, 0])), ("  U mfma+scatter+aug", us(tt[:, 5] - tt[:, 4])),
                     ("  wait tiles + scores(0)", us(tt[:, 1] - tt[:, 5])), ("prologue", us(tt[:, 1] - tt[:, 0])),
                     ("7-tile loop", us(tt[:, 2] - tt[:, 1])), ("output", us(tt[:, 3] - tt[:, 2])), ("total", us(tt[:, 3] - tt[:, 0]))):
