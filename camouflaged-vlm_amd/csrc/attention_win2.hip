@@ -61,7 +61,7 @@ constexpr OneHotImage2 make_onehot_image2() {
 __device__ const OneHotImage2 g_onehot2 = make_onehot_image2();
 
 __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_args g, const int nwx, const int npairs) {
-    constexpr int HD = 80, KS = 5, ND = 3, CPR = 10, KP = 80, VP = 80, L = 14, S_SEQ = 196;
+    constexpr int HD = 80, KS = 5, NDB = 5, CPR = 10, KP = 80, VP = 80, L = 14, S_SEQ = 196;
     constexpr int KT = 32, NKT = 7, NCW = 7;                        // 7 key tiles, 7 consumer waves
     constexpr int PLANE_B = 5120, SLOT_B = 2 * PLANE_B, IPP = 5;    // 32 rows x 160 B per plane = five 1-KiB DMA pieces
     constexpr int OFF_K = 0, OFF_V = 3 * SLOT_B, OFF_T = 6 * SLOT_B;
@@ -195,7 +195,10 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
     auto k_slot = [&](int gt) -> const unsigned char* { return smem + OFF_K + (gt % 3) * SLOT_B; };
     auto v_slot = [&](int gt) -> const unsigned char* { return smem + OFF_V + (gt % 3) * SLOT_B; };
     const int tg = lane >> 4, ti = lane & 15;
-    const int v_lane_off = (4 * (tg >> 1) + (ti >> 2)) * VP + 16 * (tg & 1) + 4 * (ti & 3);
+    // V^T fragment of the 16x16x32 shape by transposing reads: key group tg holds k-slots {a..a+3, a+8..a+11}, a = 16 (tg & 1) +
+    // 4 (tg >> 1) -- the key order v_permlane16_swap leaves in the P operands (attention_g64pp.hip); a 16-lane group reads 4 keys
+    // x 16 dims and each lane receives its dim (lane & 15) for those 4 keys
+    const int v_lane_off = (16 * (tg & 1) + 4 * (tg >> 1) + (ti >> 2)) * VP + 4 * (ti & 3);
     typedef std::integral_constant<bool, false> no_c;
     typedef std::integral_constant<bool, true> yes_c;
     bool first = true;
@@ -225,7 +228,6 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
         const int pair = pair_of(k);
         const int head = pair % g.heads, b = (pair / g.heads) / nwin;
         const int gt0 = k * NKT;
-        const int qtok = token_of(pair, qs);
         half8 qh[KS + 2], ql[KS + 2];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { qh[ks] = qn_h[ks]; ql[ks] = qn_l[ks]; }
@@ -285,11 +287,14 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
         }
 
         float m_run = -INFINITY, l_run = 0.f;
-        floatx16 o[ND];
+        // O^T as 16 x 16 tiles of the 16x16x32 MFMA (as in attention_g64pp.hip): [16-dim block][query block], this lane holds dims
+        // 16 db + 4 (lane >> 4) + j of query 16 qb + (lane & 15): head_dim 80 = 5 blocks, no padding to 96 (15 instead of 18
+        // matrix units per key tile), on the cheaper MFMA shape
+        floatx4 o[NDB][2];
 #pragma unroll
-        for (int n = 0; n < ND; ++n)
+        for (int n = 0; n < NDB; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+            for (int qb = 0; qb < 2; ++qb) o[n][qb] = floatx4{0.f, 0.f, 0.f, 0.f};
 
         // S^T tile of key tile t of this pair (stream tile gt0 + t): 15 + 4 (bias) MFMAs
         auto scores = [&](int t, auto last_c) -> floatx16 {
@@ -334,17 +339,16 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
             floatx16 s_next;
             if (HAS_NEXT) s_next = scores(t + 1, next_last_c);
             const unsigned vaddr = (unsigned)(size_t)(LDS_AS const unsigned char*)v_slot(gt0 + t) + 2u * (unsigned)v_lane_off;
-            auto read_v = [&](auto k2_c, half4 (&v0)[ND][2], half4 (&v1)[ND][2]) {
-                constexpr int K2 = decltype(k2_c)::value;
-                v0[0][0] = lds_read_tr16<2 * (16 * K2 * VP + 0)>(vaddr);       v1[0][0] = lds_read_tr16<2 * (16 * K2 * VP + 0 + 8 * VP)>(vaddr);
-                v0[1][0] = lds_read_tr16<2 * (16 * K2 * VP + 32)>(vaddr);      v1[1][0] = lds_read_tr16<2 * (16 * K2 * VP + 32 + 8 * VP)>(vaddr);
-                v0[2][0] = lds_read_tr16<2 * (16 * K2 * VP + 64)>(vaddr);      v1[2][0] = lds_read_tr16<2 * (16 * K2 * VP + 64 + 8 * VP)>(vaddr);
-                v0[0][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 0)>(vaddr);  v1[0][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 0 + 8 * VP)>(vaddr);
-                v0[1][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 32)>(vaddr); v1[1][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 32 + 8 * VP)>(vaddr);
-                v0[2][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 64)>(vaddr); v1[2][1] = lds_read_tr16<PLANE_B + 2 * (16 * K2 * VP + 64 + 8 * VP)>(vaddr);
+            // V^T fragments of dim block DB: [plane] = two transposed 8-byte reads (keys a.. and a + 8..), immediate offsets
+            auto read_v = [&](auto db_c, half4 (&v0)[2], half4 (&v1)[2]) {
+                constexpr int DB = decltype(db_c)::value;
+                v0[0] = lds_read_tr16<2 * (16 * DB)>(vaddr);                 v1[0] = lds_read_tr16<2 * (16 * DB + 8 * VP)>(vaddr);
+                v0[1] = lds_read_tr16<PLANE_B + 2 * (16 * DB)>(vaddr);       v1[1] = lds_read_tr16<PLANE_B + 2 * (16 * DB + 8 * VP)>(vaddr);
             };
-            half4 va0[ND][2], va1[ND][2], vb0[ND][2], vb1[ND][2];
-            read_v(std::integral_constant<int, 0>{}, va0, va1);         // in flight under the softmax
+            half4 va0[3][2], va1[3][2], vb0[2][2], vb1[2][2];
+            read_v(std::integral_constant<int, 0>{}, va0[0], va1[0]);   // dim blocks 0..2: in flight under the softmax
+            read_v(std::integral_constant<int, 1>{}, va0[1], va1[1]);
+            read_v(std::integral_constant<int, 2>{}, va0[2], va1[2]);
             const floatx16 s = s_cur;
             float mx = fmaxf(s[0], s[1]);
 #pragma unroll
@@ -361,37 +365,50 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                 acc += z[i];
             }
             l_run = l_run * alpha + (acc.x + acc.y);
+            {   // the O^T tiles hold queries (lane & 15) + 16 qb: this lane's own factor serves one block, the lane 16 away holds the other
+                const auto ax = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, alpha), __builtin_bit_cast(unsigned, alpha), false, false);
+                const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
 #pragma unroll
-            for (int n = 0; n < ND; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+                for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
+            }
             m_run = m_new;
-            half8 ph[2], pl[2];
+            // P (hi truncated by cvt_pkrtz, lo = e - hi: exact remainder): first / last eight values of the lane, register by register
+            // through v_permlane16_swap -> the B operands of query blocks 0 and 1
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 xh[2], xl[2];
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2)
+            for (int p2 = 0; p2 < 4; ++p2) {
+                const f32x2 e0 = z[p2], e1 = z[4 + p2];
+                const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0.x, e0.y));
+                const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e1.x, e1.y));
+                const half2v f0 = __builtin_bit_cast(half2v, h0), f1 = __builtin_bit_cast(half2v, h1);
+                const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0.x - (float)f0[0], e0.y - (float)f0[1]));
+                const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e1.x - (float)f1[0], e1.y - (float)f1[1]));
+                const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
+                const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+                xh[0][p2] = (unsigned)rh[0]; xh[1][p2] = (unsigned)rh[1];
+                xl[0][p2] = (unsigned)rl[0]; xl[1][p2] = (unsigned)rl[1];
+            }
+            auto pv = [&](int db, half4 (&v0)[2], half4 (&v1)[2]) {
+                const half8 vh = half8{v0[0][0], v0[0][1], v0[0][2], v0[0][3], v1[0][0], v1[0][1], v1[0][2], v1[0][3]};
+                const half8 vl = half8{v0[1][0], v0[1][1], v0[1][2], v0[1][3], v1[1][0], v1[1][1], v1[1][2], v1[1][3]};
 #pragma unroll
-                for (int p2 = 0; p2 < 4; ++p2) {                      // hi truncated (cvt_pkrtz), lo = e - hi: exact remainder
-                    const f32x2 e = z[4 * k2 + p2];
-                    const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x, e.y));
-                    const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x - (float)h[0], e.y - (float)h[1]));
-                    ph[k2][2 * p2] = h[0]; ph[k2][2 * p2 + 1] = h[1];
-                    pl[k2][2 * p2] = l[0]; pl[k2][2 * p2 + 1] = l[1];
-                }
-            auto pv = [&](int k2, half4 (&v0)[ND][2], half4 (&v1)[ND][2]) {
-#pragma unroll
-                for (int n = 0; n < ND; ++n) {
-                    const half8 vh = half8{v0[n][0][0], v0[n][0][1], v0[n][0][2], v0[n][0][3], v1[n][0][0], v1[n][0][1], v1[n][0][2], v1[n][0][3]};
-                    const half8 vl = half8{v0[n][1][0], v0[n][1][1], v0[n][1][2], v0[n][1][3], v1[n][1][0], v1[n][1][1], v1[n][1][2], v1[n][1][3]};
-                    o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[k2], o[n], 0, 0, 0);
-                    o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[k2], o[n], 0, 0, 0);
-                    o[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[k2], o[n], 0, 0, 0);
+                for (int qb = 0; qb < 2; ++qb) {
+                    const half8 bh = __builtin_bit_cast(half8, xh[qb]), bl = __builtin_bit_cast(half8, xl[qb]);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bh, o[db][qb], 0, 0, 0);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, bh, o[db][qb], 0, 0, 0);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bl, o[db][qb], 0, 0, 0);
                 }
             };
-            lds_wait();                                               // step-0 fragments (and everything older) are in registers
-            read_v(std::integral_constant<int, 1>{}, vb0, vb1);         // in flight under the first nine MFMAs
-            pv(0, va0, va1);
+            lds_wait();                                               // blocks 0..2 (and everything older) are in registers
+            read_v(std::integral_constant<int, 3>{}, vb0[0], vb1[0]);   // blocks 3, 4: in flight under the first 18 MFMAs
+            read_v(std::integral_constant<int, 4>{}, vb0[1], vb1[1]);
+            pv(0, va0[0], va1[0]);
+            pv(1, va0[1], va1[1]);
+            pv(2, va0[2], va1[2]);
             lds_wait();
-            pv(1, vb0, vb1);
+            pv(3, vb0[0], vb1[0]);
+            pv(4, vb0[1], vb1[1]);
             if (HAS_NEXT) s_cur = s_next;
         };
 #pragma unroll 1
@@ -400,42 +417,51 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
         if (k + 1 < my_items) load_q(pair_of(k + 1));
         tile(NKT - 1, no_c{}, no_c{});
 
-        // ---- output: 16-byte stores (v_permlane32_swap pairs, see attention_win.hip)
+        // ---- output.  A lane holds dims 16 db + 4 g .. + 3 of queries (lane & 15) + 16 qb; one v_permlane16_swap per register
+        // pair hands a neighbouring 4-dim piece across (even g: the next four dims of block db from lane + 16; odd g: the four
+        // dims below of block db + 1 from lane - 16), so blocks (0, 1) and (2, 3) leave in 16-byte stores, block 4 in 8-byte ones
         const float l_tot = half_swap_sum(l_run);
         const float inv = 1.0f / l_tot;
-        const bool st_ok = qvalid && qtok >= 0;
-        const int64_t orow = ((int64_t)b * SI + (st_ok ? qtok : 0)) * D + head * HD;
-        half_t* oh = (half_t*)g.out_hi + orow;
-        half_t* ol = g.out_lo ? (half_t*)g.out_lo + orow : nullptr;
+        const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
+        const float invq[2] = {__builtin_bit_cast(float, (unsigned)ix[0]), __builtin_bit_cast(float, (unsigned)ix[1])};
+        const int g4 = lane >> 4;
 #pragma unroll
-        for (int n = 0; n < ND; ++n)
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qs2 = wave * 32 + 16 * qb + (lane & 15);
+            const int tok2 = token_of(pair, qs2 < S_SEQ ? qs2 : S_SEQ - 1);
+            const bool ok2 = qs2 < S_SEQ && tok2 >= 0;
+            const int64_t orow = ((int64_t)b * SI + (ok2 ? tok2 : 0)) * D + head * HD;
+            half_t* oh = (half_t*)g.out_hi + orow;
+            half_t* ol = (half_t*)g.out_lo + orow;
+            unsigned ph2[NDB][2][2];                                  // [block][plane][dword]: this lane's 4 dims as packed halves
 #pragma unroll
-            for (int rp = 0; rp < 2; ++rp) {
-                if (32 * n + 16 * rp < HD) {                          // compile-time
-                    unsigned xe[2][2], xo[2][2];                      // [plane][dword] of the even / odd 8-dim group
+            for (int n = 0; n < NDB; ++n) {
+                half_t h[4], l4[4];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        half_t h[4], l4[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) split_h2(o[n][4 * (2 * rp + e) + j] * inv, h[j], l4[j]);
-                        unsigned (&x)[2][2] = e ? xo : xe;
-                        x[0][0] = __builtin_bit_cast(unsigned, half2v{h[0], h[1]});
-                        x[0][1] = __builtin_bit_cast(unsigned, half2v{h[2], h[3]});
-                        x[1][0] = __builtin_bit_cast(unsigned, half2v{l4[0], l4[1]});
-                        x[1][1] = __builtin_bit_cast(unsigned, half2v{l4[2], l4[3]});
-                    }
-                    const int d = 32 * n + 16 * rp + 8 * half;       // lower lanes: the even group, upper lanes: the odd group
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        const auto r0 = __builtin_amdgcn_permlane32_swap(xe[pl][0], xo[pl][0], false, false);
-                        const auto r1 = __builtin_amdgcn_permlane32_swap(xe[pl][1], xo[pl][1], false, false);
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 v = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
-                        half_t* dst = pl ? ol : oh;
-                        if (st_ok && dst) *(u32x4*)(dst + d) = v;
-                    }
-                }
+                for (int j = 0; j < 4; ++j) split_h2(o[n][qb][j] * invq[qb], h[j], l4[j]);
+                ph2[n][0][0] = __builtin_bit_cast(unsigned, half2v{h[0], h[1]});
+                ph2[n][0][1] = __builtin_bit_cast(unsigned, half2v{h[2], h[3]});
+                ph2[n][1][0] = __builtin_bit_cast(unsigned, half2v{l4[0], l4[1]});
+                ph2[n][1][1] = __builtin_bit_cast(unsigned, half2v{l4[2], l4[3]});
             }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                half_t* dst = pl ? ol : oh;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {                      // block pairs (0, 1) and (2, 3)
+                    const auto r0 = __builtin_amdgcn_permlane16_swap(ph2[2 * pr][pl][0], ph2[2 * pr + 1][pl][0], false, false);
+                    const auto r1 = __builtin_amdgcn_permlane16_swap(ph2[2 * pr][pl][1], ph2[2 * pr + 1][pl][1], false, false);
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = u32x4{(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+                    // even g: own piece of block 2 pr, then lane + 16's piece -> dims 4 g .. 4 g + 7 of that block;
+                    // odd g: lane - 16's piece of block 2 pr + 1, then the own one -> dims 4 (g - 1) .. 4 g + 3 of that block
+                    const int d = (g4 & 1) ? 16 * (2 * pr + 1) + 4 * (g4 - 1) : 16 * (2 * pr) + 4 * g4;
+                    if (ok2) *(u32x4*)(dst + d) = v;
+                }
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                if (ok2) *(u32x2*)(dst + 64 + 4 * g4) = u32x2{ph2[4][pl][0], ph2[4][pl][1]};
+            }
+        }
     }
     if (first) step_barrier();                                        // a workgroup without pairs still meets the producer at B_start
 }
