@@ -318,17 +318,17 @@ class Roofline:
             S = rs[0][3]
             kern = {"global": "attn_g64pair_kernel (ViT-H global attention, 64x64 map)" if S == 4096 else
                               f"global-attention kernel, S = {S} ({int(S ** 0.5)}x{int(S ** 0.5)} map)",
-                    "window": "attn_win14_kernel (ViT-H 14x14 window attention)"}[name]
+                    "window": "attn_win14p_kernel (ViT-H 14x14 window attention, producer / consumer form)"}[name]
             f_, m_ = sum(r[0] for r in rs), sum(r[1].elapsed_time(r[2]) for r in rs)
             tf = f_ / (m_ * 1e-3) / 1e12
-            issued_factor = self.split * (1.0 + 0.5 * (96.0 / 80.0 - 1.0)) if self.split == 3 else 1.0
+            issued_factor = float(self.split)               # P.V runs on 16-wide output tiles since round 3: no padding of head dim 80
             secondary.append({"kernel": kern, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                               "issued": round(tf * issued_factor, 1), "frac_issued": round(tf * issued_factor / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                               "launches": len(rs), "avg_launch_us": round(1e3 * m_ / len(rs), 2),
                               "algorithmic_gflop_per_launch": round(f_ / len(rs) / 1e9, 3),
                               "note": "achieved / frac: algorithmic FLOPs (4*S^2*hd per head, SURVEY.md §8d); issued: the MFMA flops the "
-                                      "exact mode executes for them (3 f16 products per multiply; P.V on head dim 80 padded to 96)"})
+                                      "exact mode executes for them (3 f16 products per multiply; round 2 also padded head dim 80 to 96 in P.V)"})
         return {"kernel": "gemm_nt_kernel<split=%d>" % self.split, "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
