@@ -6,7 +6,8 @@
 // global->LDS DMA (global_load_lds_dwordx4):
 //   NSTAGE = 2: one tile ahead, __syncthreads() per K-tile (drains the DMA);
 //   NSTAGE = 3: two tiles ahead, counted s_waitcnt vmcnt(N) + raw s_barrier so the newest tile's DMA
-//               stays in flight across the barrier (guide §5 "Pipelining across barriers").
+//               stays in flight across the barrier (guide §5 "Pipelining across barriers");
+//   NSTAGE = 13, 14, 15: the same ring with 3, 4, 5 slots (small grids: latency of cold weights, not issue, bounds them).
 // The LDS image is lane-linear (DMA constraint); bank conflicts of the ds_read_b128 fragment reads
 // are removed by permuting the 16-byte chunks of each 64-byte row on the *source* address and
 // applying the same involution on the read (guide §5.4 rule 21).
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     // between the MFMA groups so the load issue (readfirstlane + m0 + TA acceptance, ~100 cycles each)
     // hides in the matrix pipe's shadow instead of stalling all waves right after the barrier.
     constexpr int NG = (BK / 32) * MT;                               // MFMA groups (one per (k-step, m-tile))
+    constexpr int MG = (MT % 4 == 0) ? 4 : (MT % 3 == 0 ? 3 : (MT % 2 == 0 ? 2 : 1));   // m-tiles whose fragments are held at once
     auto compute = [&](int slot, int tn, int sn) {
         if (DBG == 2) {
             if (tn >= 0) issue(tn, sn);
@@ -238,25 +240,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 if (SPLIT == 3) wl[i] = *(const half8*)(pWlo + w_row + i * 16 * ROWB + co);
             }
 #pragma unroll
-            for (int mh = 0; mh < MT / 4; ++mh) {                   // 4 m-tiles at a time keeps fragments at 64 VGPRs
-                half8 ah[4], al[4];
+            for (int mh = 0; mh < MT / MG; ++mh) {                  // 4 m-tiles at a time keeps fragments at 64 VGPRs
+                half8 ah[MG], al[MG];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ah[i] = *(const half8*)(pAhi + a_row + (mh * 4 + i) * 16 * ROWB + co);
-                    if (SPLIT == 3) al[i] = *(const half8*)(pAlo + a_row + (mh * 4 + i) * 16 * ROWB + co);
+                for (int i = 0; i < MG; ++i) {
+                    ah[i] = *(const half8*)(pAhi + a_row + (mh * MG + i) * 16 * ROWB + co);
+                    if (SPLIT == 3) al[i] = *(const half8*)(pAlo + a_row + (mh * MG + i) * 16 * ROWB + co);
                 }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+                for (int mt = 0; mt < MG; ++mt) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        floatx4 c = acc[mh * 4 + mt][nt];
+                        floatx4 c = acc[mh * MG + mt][nt];
                         if (SPLIT == 3) {
                             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt], ah[mt], c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], al[mt], c, 0, 0, 0);
                         }
-                        acc[mh * 4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
+                        acc[mh * MG + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[nt], ah[mt], c, 0, 0, 0);
                     }
-                    const int gidx = (ks * (MT / 4) + mh) * 4 + mt;
+                    const int gidx = (ks * (MT / MG) + mh) * MG + mt;
                     // DMA pieces go out during the first half of the MFMA groups: the last piece then has half a
                     // K-tile of MFMA time to land before the end-of-tile wait
                     constexpr int NGI = (NSTAGE == 2 && NG >= 2) ? NG / 2 : NG;
@@ -410,8 +412,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         if (DBG == 8 && grpB) __builtin_amdgcn_s_setprio(1);          // probe: static priority for the younger half
         const int co = chunk_off(0);
         static_assert(NSTAGE != 5 || (MT % 2) == 0, "staggered loop: the m-tiles of a wave split into two halves");
-        constexpr int MH = MT / 2;                                     // m-tiles per phase (4 for the 256-row tile, 3 for the 192-row one)
-        half8 wh[4], wl[4], ah[MH > 0 ? MH : 1], al[MH > 0 ? MH : 1];
+        constexpr int MH = MT >= 2 ? MT / 2 : 1;                                     // m-tiles per phase (4 for the 256-row tile, 3 for the 192-row one)
+        half8 wh[4], wl[4], ah[MH], al[MH];
         auto mfma_half = [&](int mh, int tn, int sn) {           // MH m-tiles; optional DMA of tile tn into slot sn
             const bool dma = tn >= 0 && tn < nk && DBG != 1;
             const int64_t koff = (int64_t)tn * BK;
@@ -483,20 +485,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         }
         if (!grpB) __builtin_amdgcn_s_barrier();                  // match B's extra leading barrier
     } else {
-        // 3-slot ring: tile t computes from slot t%3 while tiles t+1 and t+2 are in flight / landing.
-        issue(0, 0);
-        if (nk > 1) { issue(1, 1); wait_vmcnt<PER_WAVE>(); } else { wait_vmcnt<0>(); }
+        // R-slot ring (R = 3, or NSTAGE - 10 for the deep rings of the small-grid launches): tile t computes from slot t % R while
+        // tiles t+1 .. t+R-1 are in flight / landing.  The deep form is for grids that leave most of the chip idle (one image: the
+        // CLIP towers at M = 581 are 40 tiles of 128^2): such a workgroup is alone on its CU, its weights come cold from HBM
+        // (~2 us per round trip against 0.37 us of MFMAs per K-tile), and the time of the launch is K-tiles x latency / depth.
+        constexpr int R = NSTAGE >= 13 ? NSTAGE - 10 : 3;
+        static_assert((R - 1) * PER_WAVE < 64, "vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int i = 0; i < R - 1; ++i)
+            if (i < nk) issue(i, i);
+        // tile 0 landed; the (up to R - 2) younger tiles stay in flight
+        if (nk >= R - 1) wait_vmcnt<(R - 2) * PER_WAVE>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         int slot = 0;
         for (int t = 0; t < nk; ++t) {
-            int s2 = slot + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
-            // slot s2 held tile t-1: all waves left it at the last barrier
-            compute(slot, t + 2 < nk ? t + 2 : -1, s2);
-            // tile t+1 must have landed for every wave before anyone reads it; only tile t+2 may stay in flight
-            if (t + 2 < nk) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+            const int sp = slot == 0 ? R - 1 : slot - 1;
+            // slot sp held tile t-1: all waves left it at the last barrier
+            compute(slot, t + R - 1 < nk ? t + R - 1 : -1, sp);
+            // tile t+1 must have landed for every wave before anyone reads it; the tiles behind it may stay in flight
+            const int younger = nk - 2 - t;                      // tiles issued after tile t+1 (at most R - 2)
+            if (younger >= R - 2) wait_vmcnt<(R - 2) * PER_WAVE>();
+            else if (R > 3 && younger == R - 3) wait_vmcnt<(R > 3 ? R - 3 : 0) * PER_WAVE>();
+            else if (R > 4 && younger == R - 4) wait_vmcnt<(R > 4 ? R - 4 : 0) * PER_WAVE>();
+            else wait_vmcnt<0>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            slot = slot + 1 == 3 ? 0 : slot + 1;
+            slot = slot + 1 == R ? 0 : slot + 1;
         }
     }
 
@@ -695,7 +709,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             // floats per staged row: 64 + 4 pad; PERSIST: 64, the 16-byte chunks of row r permuted by ^ r instead (the ring
             // keeps its 128 KB, so the slabs of the 8 waves have to fit the last 32 KB of the CU's 160)
             constexpr int EP = PERSIST ? 64 : 68;
-            constexpr int LDS_BYTES = (NSTAGE == 6 ? 1 : (NSTAGE >= 4 ? 2 : NSTAGE)) * STAGE;
+            constexpr int LDS_BYTES = (NSTAGE >= 13 ? NSTAGE - 10 : NSTAGE == 6 ? 1 : (NSTAGE >= 4 ? 2 : NSTAGE)) * STAGE;
             constexpr int NBUF = (!PERSIST && LDS_BYTES >= NWAVE * 2 * 16 * EP * 4) ? 2 : 1;   // two slabs in flight when LDS allows
             float* ebuf = (float*)(smem + (PERSIST ? 2 * STAGE : 0)) + wave * (NBUF * 16 * EP);
             auto sw = [&](int row, int chunk) -> int { return PERSIST ? ((chunk ^ row) << 2) : (chunk << 2); };   // float offset of a 16-byte chunk
@@ -1141,7 +1155,19 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     // Per-workgroup cost = t0 + K * c(fill), c rising linearly with the fill of the workgroup slots; fitted on the eight shapes of
     // tools/ab_gemm.py SHAPES=b1 (profiles/r03_ab_gemm_b1.log: the model picks the measured winner for each).
     p.sk_parts = 1;
+    // 128^2 launches of a small grid (whole or in K-parts) run the deep ring: see the R-slot loop of the kernel
+    static int ring_env = env_int("CVLM_GEMM_RING", 4);
+    if (live_env) ring_env = env_int("CVLM_GEMM_RING", 4);
+    // ... with eight waves of 32 x 64 instead of four of 64 x 64 (CVLM_GEMM_W8): a wave issues one KiB of DMA per ~100 cycles, and
+    // with the chip mostly idle it is the issue of a K-tile's 32 DMA instructions by four waves (800 cycles against 768 of MFMAs),
+    // not the matrix pipe, that a workgroup waits for
+    // CVLM_GEMM_W8: 0 four waves of 64 x 64; 1 (default) eight waves, 64 x 128 tiles when those fit one round of workgroups, else
+    // 128^2; 2 / 3 force the 64-row / 128-row form (A/B tools)
+    static int w8_env = env_int("CVLM_GEMM_W8", 1);
+    if (live_env) w8_env = env_int("CVLM_GEMM_W8", 1);
+    auto pick_ring = [&](long wgs) { return (wgs <= 256 && ring_env >= 3 && ring_env <= 5) ? ring_env : 0; };
     int small_tail_S = 0;                                             // > 0: K-parts of the 256^2 tail chain chosen here
+    int small_ring = 0;                                               // > 0: slots of the deep LDS ring for a 128^2 launch of a small grid
     static int sk_env = env_int("CVLM_GEMM_SK", 1), small_env = env_int("CVLM_GEMM_SMALL", 1);
     if (live_env) { sk_env = env_int("CVLM_GEMM_SK", 1); small_env = env_int("CVLM_GEMM_SMALL", 1); }
     if (g.split == 3 && !conv && p.a.batch == 1 && g.M <= 4096 && small_env != 0 && (variant_env == 0 || (variant_env == 1 && sk_env > 1))) {
@@ -1151,7 +1177,12 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         const long t5 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
         auto fillc = [](double lo, double hi, double wgs, double slots) { const double f = wgs / slots; return lo + (hi - lo) * (f < 1.0 ? f : 1.0); };
         auto over = [](double wgs, double slots) { const double r = wgs / slots; return r > 1.0 ? r : 1.0; };
-        const double m1 = 4.0 + K * fillc(0.021, 0.054, (double)t1, 512.0) * over((double)t1, 512.0);
+        // 128^2 family: under one round of workgroups the deep-ring / eight-wave kernels run (0.78 of the fitted two-slot cost per K;
+        // 0.62 with 64 x 128 tiles when those still fit one round), tools/ab_gemm.py SHAPES=b1 COLD=1
+        const long t64 = (long)((g.M + 63) / 64) * ((g.N + 127) / 128);
+        const bool ring_on = ring_env == 4 && w8_env != 0;
+        const double k1 = !ring_on || t1 > 256 ? 1.0 : (t64 <= 256 && w8_env != 3 ? 0.62 : 0.78);
+        const double m1 = 4.0 + k1 * K * fillc(0.021, 0.054, (double)t1, 512.0) * over((double)t1, 512.0);
         const double m2 = 4.0 + K * fillc(0.028, 0.047, (double)t2, 256.0) * over((double)t2, 256.0);
         // 256^2 tiles: full rounds at the fitted tile time, the last round whole or cut into S chained K-parts
         const long full5 = t5 / 256, rem5 = t5 % 256;
@@ -1177,7 +1208,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             for (int S = 2; S <= 8; ++S) {
                 if (g.K / 32 < 4 * S || (size_t)t1 * S * 128 * 128 * sizeof(float) > TAIL_WS_BYTES) break;
                 const double wg = (double)(t1 * S);
-                const double t = 4.0 + (K / S) * fillc(0.021, 0.054, wg, 512.0) * over(wg, 512.0) + 6.0 + 2.0 * S + 0.052 * wg;
+                const double t = 4.0 + (ring_on && wg <= 256.0 ? 0.78 : 1.0) * (K / S) * fillc(0.021, 0.054, wg, 512.0) * over(wg, 512.0) + 6.0 + 2.0 * S + 0.052 * wg;
                 if (t < msk) { msk = t; skS = S; }
             }
         }
@@ -1199,15 +1230,25 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             p.sk_parts = skS;
         }
         if (p.sk_parts > 1) {
+            small_ring = pick_ring(t1 * p.sk_parts);
+            if (small_ring > 4) small_ring = 4;                          // five slots are the whole LDS; this kernel has a static word beside them
             p.flags = (unsigned*)g.workspace;
             p.ws = (float*)((unsigned char*)g.workspace + TAIL_FLAG_BYTES);
             p.nbx = (g.N + 127) / 128; p.nby = (g.M + 127) / 128;
-            constexpr int smem_sk = 2 * 2 * (128 + 128) * 32 * 2;
-            auto ksk = gemm_nt_kernel<3, 2, 2, 2, 32, 0, 4, false, -1, false, true>;
-            static bool attr_sk[16] = {};
-            if (cvlm_first_on_device(attr_sk))
-                (void)hipFuncSetAttribute((const void*)ksk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);
-            hipLaunchKernelGGL(ksk, dim3(p.nbx * p.nby * p.sk_parts, 1), dim3(256), smem_sk, s, p);
+#define CVLM_LAUNCH_SK(WM_, MT_, NS_, SLOTS_)                                                                       \
+    do {                                                                                                            \
+        constexpr int smem_sk = SLOTS_ * 2 * (128 + 128) * 32 * 2;                                                  \
+        auto ksk = gemm_nt_kernel<3, WM_, 2, NS_, 32, 0, MT_, false, -1, false, true>;                              \
+        static bool attr_sk[16] = {};                                                                               \
+        if (cvlm_first_on_device(attr_sk))                                                                          \
+            (void)hipFuncSetAttribute((const void*)ksk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);      \
+        hipLaunchKernelGGL(ksk, dim3(p.nbx* p.nby * p.sk_parts, 1), dim3(WM_ * 2 * 64), smem_sk, s, p);             \
+    } while (0)
+            if (small_ring == 4 && w8_env) CVLM_LAUNCH_SK(4, 2, 14, 4);
+            else if (small_ring == 3) CVLM_LAUNCH_SK(2, 4, 13, 3);
+            else if (small_ring == 4) CVLM_LAUNCH_SK(2, 4, 14, 4);
+            else CVLM_LAUNCH_SK(2, 4, 2, 2);
+#undef CVLM_LAUNCH_SK
             CVLM_CHECK_LAUNCH();
             return 0;
         }
@@ -1216,7 +1257,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #define CVLM_LAUNCH_D(SPLIT, WM, WN, NS, BKT, DBG, MT)                                                        \
     do {                                                                                                      \
         constexpr int NPA_ = (SPLIT == 3) ? 2 : 1;                                                            \
-        constexpr int smem_ = (NS == 6 ? 1 : (NS >= 4 ? 2 : NS)) * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
+        constexpr int smem_ = (NS >= 13 ? NS - 10 : NS == 6 ? 1 : (NS >= 4 ? 2 : NS)) * NPA_ * (WM * MT * 16 + WN * 64) * BKT * 2;                                      \
         p.nbx = (g.N + WN * 64 - 1) / (WN * 64);                                                              \
         p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                            \
         auto kern_ = gemm_nt_kernel<SPLIT, WM, WN, NS, BKT, DBG, MT>;                                                     \
@@ -1349,6 +1390,12 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 25) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 2, 8);
         else if (variant == 3) CVLM_LAUNCH(3, 2, 2, 3);
 #endif
+        else if (variant == 1 && !conv && p.a.batch == 1 && g.M <= 4096 && (small_ring = pick_ring((long)((g.M + 127) / 128) * ((g.N + 127) / 128))) == 3) CVLM_LAUNCH(3, 2, 2, 13);
+        else if (small_ring == 4 && (w8_env == 2 || (w8_env == 1 && (long)((g.M + 63) / 64) * ((g.N + 127) / 128) <= 256)))
+            CVLM_LAUNCH_D(3, 4, 2, 14, 32, 0, 1);                            /* 64 x 128 tiles, eight waves of 16 x 64 */
+        else if (small_ring == 4 && w8_env) CVLM_LAUNCH_D(3, 4, 2, 14, 32, 0, 2);   /* 128^2 tiles, eight waves of 32 x 64 */
+        else if (small_ring == 4) CVLM_LAUNCH(3, 2, 2, 14);
+        else if (small_ring == 5) CVLM_LAUNCH(3, 2, 2, 15);
         else CVLM_LAUNCH(3, 2, 2, 2);
     } else {
         if (group_env > 0) p.group_m = group_env;

@@ -126,6 +126,33 @@ def test_gemm_tail_split(hip, M, N, K, why, monkeypatch):
     assert int(ws[:2048].view(torch.int32).abs().sum()) == 0                           # hand-off words are back to zero
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(581, 1024, 1024, "0"), (581, 1024, 4096, "4"), (300, 264, 96, "0"), (581, 3072, 1024, "0"),
+                                       (130, 1024, 64, "0"), (581, 1024, 1024, "1")])
+def test_gemm_small_grid_ring_depth(hip, monkeypatch, M, N, K, sk):
+    """Small grids run the 128^2 kernels over a deep LDS ring (CVLM_GEMM_RING slots, 3-5 K-tiles of DMA in flight: cold weights
+    bound a workgroup that has its CU to itself).  The depth changes when a K-tile is fetched, never the order of the
+    accumulation: every depth gives the bits of the two-slot loop, for whole tiles and for K-parts, K-tile counts below and above
+    the depth included."""
+    a, w, bias = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    ref = A.float().cpu().double() @ W.float().cpu().double().t() + bias.double()
+    ws = hip.new_gemm_workspace("cuda")
+    monkeypatch.setenv("CVLM_GEMM_SK", sk)
+    outs = {}
+    for ring, w8 in (("2", "0"), ("3", "0"), ("4", "0"), ("5", "0"), ("4", "1"), ("4", "2"), ("4", "3")):   # w8: eight waves; 2: 64 x 128 tiles, 3: 128^2 tiles, 1: the launcher's pick
+        monkeypatch.setenv("CVLM_GEMM_RING", ring)
+        monkeypatch.setenv("CVLM_GEMM_W8", w8)
+        o = torch.full((M, N), float("nan"), device="cuda")
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=o, workspace=ws)
+        torch.cuda.synchronize()
+        assert relerr(o.cpu().double(), ref) < 3e-6, (ring, w8)
+        outs[ring + w8] = o
+    for k in ("30", "40", "50", "41", "42", "43"):
+        assert torch.equal(outs[k], outs["20"]), k
+    assert hip.gemm_workspace_errors(ws) == 0
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,N,K,parts", [(581, 1024, 4096, 8), (581, 3072, 1024, 4), (1162, 1024, 1024, 2), (4096, 1280, 5184, 3),
                                           (300, 264, 512, 4)])
 def test_gemm_split_k_small_grids(hip, monkeypatch, M, N, K, parts):

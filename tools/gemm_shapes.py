@@ -60,6 +60,8 @@ t0.record()
 for _ in range(a.reps):
     cas.cascade(inp, ci, cm, pipelined=a.pipelined)
 t1.record()
+for n in names:                                                      # the flush (stage 2 of the last batch alone) is not part of a steady-state step
+    setattr(hip, n, orig[n])
 cas.flush()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
