@@ -39,6 +39,128 @@ __global__ __launch_bounds__(512) void k(const half8* __restrict__ frag, const h
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// Operand reuse between consecutive MFMAs (16x16x32): does the pipe draw less when one (or both) source operands of an instruction
+// are the registers the previous instruction read?  ORDER 0: both change every instruction; 1: A held for four instructions;
+// 2: A held for all eight of a group (B rotates); 3: both held for four instructions (accumulators differ).
+template <int ORDER>
+__global__ __launch_bounds__(512) void k_order(const half8* __restrict__ frag, float* out, int iters) {
+    half8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = frag[(i * 64 + (threadIdx.x & 63))]; b[i] = frag[((4 + i) * 64 + (threadIdx.x & 63))]; }
+    floatx4 acc4[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) acc4[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ia = ORDER == 0 ? (i + rep) & 3 : ORDER == 1 ? ((i >> 2) + rep) & 3 : ORDER == 2 ? rep : ((i >> 2) + rep) & 3;
+                const int ib = ORDER == 3 ? ((i >> 2) + 2 * rep) & 3 : i & 3;
+                acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ia], b[ib], acc4[i], 0, 0, 0);
+            }
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) s += acc4[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int ORDER>
+void run_order(const char* name, const half8* frag, float* out, double seconds) {
+    const int iters = 20000, threads = 512;
+    const double flop_per_launch = 256.0 * (threads / 64) * iters * 32.0 * 16384.0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k_order<ORDER><<<256, threads>>>(frag, out, iters);
+    hipDeviceSynchronize();
+    const double t0 = now();
+    int n = 0;
+    hipEventRecord(e0, 0);
+    while (now() - t0 < seconds) { for (int i = 0; i < 20; ++i) k_order<ORDER><<<256, threads>>>(frag, out, iters); n += 20; hipDeviceSynchronize(); }
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    const double t1 = now();
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    printf("CONFIG %s | waves/SIMD 2 | t0 %.3f t1 %.3f | %.1f TFLOP/s issued (f16 dense)\n", name, t0, t1, n * flop_per_launch / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
+// The split-3 GEMM's own inner block (4 x 4 output tiles of 16 x 16, three products each: lo.hi + hi.lo + hi.hi) in several
+// instruction orders; operands as in the GEMM (hi planes random, lo planes what the split leaves).
+//   PAT 0: the GEMM's order: for mt, for nt: (wl,ah) (wh,al) (wh,ah) on acc[mt][nt]           -- 2 of 3 transitions share an operand
+//   PAT 1: snake: every transition shares one operand (the triple is walked forwards / backwards alternately)
+//   PAT 2: product-major per m-tile: for nt (wh,ah); for nt (wl,ah); for nt (wh,al)            -- B held for 8, then 4 instructions
+//   PAT 3: product-major over the block: all 16 (wh,ah), all 16 (wl,ah), all 16 (wh,al)
+template <int PAT>
+__global__ __launch_bounds__(512) void k_gemm(const half8* __restrict__ hi, const half8* __restrict__ lo, float* out, int iters) {
+    half8 wh[4], wl[4], ah[4], al[4];
+    for (int i = 0; i < 4; ++i) {
+        wh[i] = hi[i * 64 + (threadIdx.x & 63)]; ah[i] = hi[(4 + i) * 64 + (threadIdx.x & 63)];
+        wl[i] = lo[i * 64 + (threadIdx.x & 63)]; al[i] = lo[(4 + i) * 64 + (threadIdx.x & 63)];
+    }
+    floatx4 acc[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+#define MF(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+    for (int it = 0; it < iters; ++it) {
+        if (PAT == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { MF(wl[nt], ah[mt], acc[mt][nt]); MF(wh[nt], al[mt], acc[mt][nt]); MF(wh[nt], ah[mt], acc[mt][nt]); }
+        } else if (PAT == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if ((nt & 1) == 0) { MF(wl[nt], ah[mt], acc[mt][nt]); MF(wh[nt], ah[mt], acc[mt][nt]); MF(wh[nt], al[mt], acc[mt][nt]); }
+                    else { MF(wh[nt], al[mt], acc[mt][nt]); MF(wh[nt], ah[mt], acc[mt][nt]); MF(wl[nt], ah[mt], acc[mt][nt]); }
+                }
+        } else if (PAT == 2) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) MF(wh[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) MF(wl[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) MF(wh[nt], al[mt], acc[mt][nt]);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) MF(wh[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) MF(wl[nt], ah[mt], acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) MF(wh[nt], al[mt], acc[mt][nt]);
+        }
+    }
+#undef MF
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int PAT>
+void run_gemm(const char* name, const half8* hi, const half8* lo, float* out, double seconds) {
+    const int iters = 4000, threads = 512;
+    const double flop_per_launch = 256.0 * (threads / 64) * iters * 48.0 * 16384.0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k_gemm<PAT><<<256, threads>>>(hi, lo, out, iters);
+    hipDeviceSynchronize();
+    const double t0 = now();
+    int n = 0;
+    hipEventRecord(e0, 0);
+    while (now() - t0 < seconds) { for (int i = 0; i < 20; ++i) k_gemm<PAT><<<256, threads>>>(hi, lo, out, iters); n += 20; hipDeviceSynchronize(); }
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    const double t1 = now();
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    printf("CONFIG %s | waves/SIMD 2 | t0 %.3f t1 %.3f | %.1f TFLOP/s issued (f16 dense)\n", name, t0, t1, n * flop_per_launch / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+}
+
 template <int SHAPE>
 void run(const char* name, int threads, const half8* frag, float* out, double seconds, const half8* fragb = nullptr) {
     if (!fragb) fragb = frag;
@@ -79,6 +201,23 @@ int main(int argc, char** argv) {
     }
     hipMalloc(&frag, sizeof(h));
     hipMemcpy(frag, h, sizeof(h), hipMemcpyHostToDevice);
+    if (argc > 2 && atoi(argv[2]) == 1) {                            // operand-reuse study only
+        run_order<0>("16x16x32 order 0: both operands change every instruction", frag, out, seconds);
+        run_order<1>("16x16x32 order 1: A held for 4 instructions", frag, out, seconds);
+        run_order<2>("16x16x32 order 2: A held for 8 instructions", frag, out, seconds);
+        run_order<3>("16x16x32 order 3: A and B held for 4 instructions", frag, out, seconds);
+        run_order<0>("16x16x32 order 0 again", frag, out, seconds);
+        return 0;
+    }
+    if (argc > 2 && atoi(argv[2]) == 2) {                            // instruction order of the split-3 GEMM block
+        const half8* hi = frag; const half8* lo = frag + 2 * 8 * 64;
+        run_gemm<0>("gemm block, order of the kernel (lo.hi, hi.lo, hi.hi per tile)", hi, lo, out, seconds);
+        run_gemm<1>("gemm block, snake (every transition shares an operand)", hi, lo, out, seconds);
+        run_gemm<2>("gemm block, product-major per m-tile", hi, lo, out, seconds);
+        run_gemm<3>("gemm block, product-major over the block", hi, lo, out, seconds);
+        run_gemm<0>("gemm block, order of the kernel again", hi, lo, out, seconds);
+        return 0;
+    }
     run<1>("16x16x32 random operands", 256, frag, out, seconds);
     run<1>("16x16x32 random operands", 512, frag, out, seconds);
     run<0>("32x32x16 random operands", 256, frag, out, seconds);

@@ -24,10 +24,13 @@ time.sleep(1.5)
 t0 = time.time(); time.sleep(2.5); print("idle:", window(t0 - 1.0, time.time() + 0.2), flush=True)
 binp = os.path.join(ROOT, "tools", "micro", "bin", "mfma_power")
 if os.path.exists(binp):
-    out = subprocess.run([binp, "4"], capture_output=True, text=True).stdout
+    order_study = os.environ.get("MFMA_ORDER") in ("1", "2")  # operand reuse between consecutive MFMAs only (mfma_power.hip k_order / k_gemm)
+    out = subprocess.run([binp, "4"] + ([os.environ["MFMA_ORDER"]] if order_study else []), capture_output=True, text=True).stdout
     for line in out.splitlines():
         m = re.search(r"t0 ([0-9.]+) t1 ([0-9.]+)", line)
         print(line.split(" | t0")[0], "|", line.split("|")[-1].strip(), "|", window(float(m.group(1)), float(m.group(2))) if m else "", flush=True)
+if os.path.exists(binp) and order_study:
+    stop = True; th.join(); sys.exit(0)
 # the product GEMM at the encoder's lin1 shape, in this process
 sys.path.insert(0, ROOT)
 import torch
