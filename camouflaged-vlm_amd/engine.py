@@ -914,6 +914,10 @@ class Cascade(_Base):
         # as ONE vision-tower forward over both batches (M = 9296 at B = 8: 36 row tiles instead of twice 18.2; out_proj 148
         # tiles on 256 CUs instead of twice 76).  CVLM_FUSE_CLIP=0 keeps the two forwards apart.
         self.fuse_clip = os.environ.get("CVLM_FUSE_CLIP", "1") == "1"
+        # Host issue order inside a step: the encoder's launches before the side stream's CLIP launches (CVLM_ENCODER_FIRST=0: the
+        # other way round, as in rounds 1-2).  It decides nothing at B = 8 (the host is far ahead of the GPU); with one image the
+        # host IS the pace of a CLIP pass and the encoder behind it started 4 ms late.
+        self.encoder_first = os.environ.get("CVLM_ENCODER_FIRST", "1") == "1"
         self._pending = None                                         # (masks, clip_image, pred, logits) of the batch whose stage 2 is still owed
         self._pending_stream = None
         self._side = None
@@ -945,10 +949,21 @@ class Cascade(_Base):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
             main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
-            feats = self.encoder.forward(inp, taps)
+            if self.encoder_first:
+                # the host issues the ENCODER's launches first: one image's CLIP pass is ~190 launches of a few workgroups each, the
+                # GPU runs them as fast as the host can issue them, and an encoder issued behind them started 4 ms late with the
+                # chip nearly idle until then (tools/step_timeline.py).  The side stream waits for the inputs, not for the encoder.
+                ready = torch.cuda.Event()
+                ready.record(main)
+                feats = self.encoder.forward(inp, taps)
+                self._side.wait_event(ready)
+                with torch.cuda.stream(self._side):
+                    img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
+            else:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
+                feats = self.encoder.forward(inp, taps)
             main.wait_stream(self._side)
         else:
             feats = self.encoder.forward(inp, taps)
@@ -991,12 +1006,22 @@ class Cascade(_Base):
         # run is about to overwrite (two buffers alternate)
         if self._done[self._parity] is not None:
             main.wait_event(self._done[self._parity])
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
-        feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
-        enc_done = torch.cuda.Event()
-        enc_done.record(main)
+        if self.encoder_first:                                       # see infer_test
+            ready = torch.cuda.Event()
+            ready.record(main)
+            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+            enc_done = torch.cuda.Event()
+            enc_done.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
+            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+            enc_done = torch.cuda.Event()
+            enc_done.record(main)
         with torch.cuda.stream(side):
             side.wait_event(enc_done)
             sparse = self.sparse_prompts(img_f, txt_f, B)
@@ -1030,23 +1055,37 @@ class Cascade(_Base):
         self._pending_stream = side
         if self._done[self._parity] is not None:                     # the batch before the previous one has left the side stream
             main.wait_event(self._done[self._parity])
-        side.wait_stream(main)
         prev = self._pending
-        with torch.cuda.stream(side):
+
+        def clip_forwards():
             if prev is None:
-                img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
-            else:
-                p_masks, p_image, p_pred, p_logits = prev
-                Bp, R = p_masks.shape[0], self.c.image_resolution
-                alpha = self.ws.f32("alpha2", Bp, 1, R, R)
-                hip.bilinear(p_masks, Bp, g.inp_size, g.inp_size, alpha, R, R, sigmoid_in=True)
-                img_n, sel, pred_all, logits_all = self.clip.forward([p_image, clip_image], [alpha, clip_mask])
-                p_pred.copy_(pred_all[:Bp])                          # results of the previous batch land in the tensors it returned
-                p_logits.copy_(logits_all[:Bp])
-                img_f, txt_f = img_n[Bp:], sel[Bp:]
-        feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
-        enc_done = torch.cuda.Event()
-        enc_done.record(main)
+                i_f, t_f, _, _ = self.clip.forward(clip_image, clip_mask)
+                return i_f, t_f
+            p_masks, p_image, p_pred, p_logits = prev
+            Bp, R = p_masks.shape[0], self.c.image_resolution
+            alpha = self.ws.f32("alpha2", Bp, 1, R, R)
+            hip.bilinear(p_masks, Bp, g.inp_size, g.inp_size, alpha, R, R, sigmoid_in=True)
+            img_n, sel, pred_all, logits_all = self.clip.forward([p_image, clip_image], [alpha, clip_mask])
+            p_pred.copy_(pred_all[:Bp])                              # results of the previous batch land in the tensors it returned
+            p_logits.copy_(logits_all[:Bp])
+            return img_n[Bp:], sel[Bp:]
+
+        if self.encoder_first and side is not main:                  # see infer_test
+            ready = torch.cuda.Event()
+            ready.record(main)
+            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+            enc_done = torch.cuda.Event()
+            enc_done.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                img_f, txt_f = clip_forwards()
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                img_f, txt_f = clip_forwards()
+            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+            enc_done = torch.cuda.Event()
+            enc_done.record(main)
         with torch.cuda.stream(side):
             side.wait_event(enc_done)
             sparse = self.sparse_prompts(img_f, txt_f, B)

@@ -6,4 +6,5 @@ rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --surface dropin --batch 1 --steps 16 --warmup 2 --no-cpu-baseline --no-roofline --no-power > $O/bench_stats.log 2>&1
 python tools/summarize_profiles.py stats $O/stats $O/r03_dropin_b1_kernel_stats.csv
 python tools/kernel_gaps.py $O/stats tail:0.25 > $O/r03_dropin_b1_kernel_gaps.log 2>&1
+python tools/step_timeline.py $O/stats 16 > $O/r03_dropin_b1_step_timeline.log 2>&1
 rm -rf $O/stats
