@@ -1098,6 +1098,40 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         group_env = env_int("CVLM_GEMM_GROUP_M", 0); tail_env = env_int("CVLM_GEMM_TAIL", 1); variant_env = env_int("CVLM_GEMM_VARIANT", 0);
         persist_env = env_int("CVLM_GEMM_PERSIST", 1);
     }
+    // ---- column split (one image): a grid of 256^2 tiles a little over one round -- lin1 of a ViT-H block at M = 4096 is 16 x 20 =
+    // 320 tiles on 256 CUs -- spends a second round (or a chain of K-parts with its slab traffic and hand-offs, 58 us) on a
+    // quarter round of work.  Two launches instead: the columns that make exactly one round of 256^2 tiles, then the rest as
+    // 128^2 tiles on the deep-ring kernel, one round of those (30-40 us).  Whole tiles both times: no slabs, no flags, and the bits
+    // of every output are those of an unsplit launch.  Plain and LayerNorm-folded epilogues only (their per-column operands just
+    // move with the column offset).
+    static thread_local int in_colsplit = 0;
+    static int colsplit_env = env_int("CVLM_GEMM_COLSPLIT", 1);
+    if (live_env) colsplit_env = env_int("CVLM_GEMM_COLSPLIT", 1);
+    if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.M <= 4096 && !h2res && g.hm_S == 0 && g.ps_c2 == 0 &&
+        variant_env == 0) {
+        const int nby = (g.M + 255) / 256, nbx = (g.N + 255) / 256;
+        const int c0 = nby > 0 ? 256 / nby : 0;                          // column tiles of the first launch: one round of tiles
+        const int n0 = c0 * 256, rest = g.N - n0;
+        const long t1r = rest > 0 ? (long)((g.M + 127) / 128) * ((rest + 127) / 128) : 0;
+        if (nbx > c0 && c0 * nby >= 232 && nbx * nby < 2 * 256 && rest >= 128 && (rest & 7) == 0 && t1r <= 256 && (n0 & 7) == 0) {
+            cvlm_gemm_args a1 = g, a2 = g;
+            a1.N = n0;
+            a2.N = rest;
+            a2.w_hi = (const char*)g.w_hi + (int64_t)n0 * g.ldw * 2;
+            if (g.w_lo) a2.w_lo = (const char*)g.w_lo + (int64_t)n0 * g.ldw * 2;
+            if (g.bias) a2.bias = g.bias + n0;
+            if (g.ln_colsum) a2.ln_colsum = g.ln_colsum + n0;
+            if (g.residual) a2.residual = g.residual + n0;
+            if (g.out_f32) a2.out_f32 = g.out_f32 + n0;
+            if (g.out_hi) a2.out_hi = (char*)g.out_hi + (int64_t)n0 * 2;
+            if (g.out_lo) a2.out_lo = (char*)g.out_lo + (int64_t)n0 * 2;
+            in_colsplit = 1;
+            int rc = cvlm_gemm(&a1, stream);
+            if (rc == 0) rc = cvlm_gemm(&a2, stream);
+            in_colsplit = 0;
+            return rc;
+        }
+    }
 #ifdef CVLM_PROBES
     p.trace = g_trace;
 #endif

@@ -126,6 +126,44 @@ def test_gemm_tail_split(hip, M, N, K, why, monkeypatch):
     assert int(ws[:2048].view(torch.int32).abs().sum()) == 0                           # hand-off words are back to zero
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 5120, 1280), (4000, 4360, 256), (3840, 4608, 64)])
+def test_gemm_column_split_one_image(hip, monkeypatch, M, N, K):
+    """One image's lin1 (4096 x 5120: 320 tiles of 256^2 on 256 CUs) goes out as two launches -- the columns that make one round of
+    256^2 tiles, the rest as 128^2 tiles (CVLM_GEMM_COLSPLIT).  Whole tiles in both: same bits as the single launch, for the plain
+    and the LayerNorm-folded epilogue, ragged M / N included."""
+    from camouflaged_vlm_amd.engine import LnLinear
+    a, w, bias = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5), rnd(N, seed=53)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    ref = A.float().cpu().double() @ W.float().cpu().double().t() + bias.double()
+    ws = hip.new_gemm_workspace("cuda")
+    XS = 0.25
+    x = rnd(M, K, seed=55) * 2.0
+    gamma, beta = 1.0 + 0.1 * rnd(K, seed=56), 0.05 * rnd(K, seed=57)
+    xh, st, mrg = hip.H2.empty(M, K), torch.empty(hip.stats_pieces(K), M, 2, device="cuda"), torch.empty(M, 2, device="cuda")
+    hip.row_stats_split(x.cuda(), XS, xh, st, M, K)
+    hip.ln_stats_merge(st, M, K, 1e-6, mrg, ws)
+    lin = LnLinear(w, bias, gamma, beta, "cuda")
+    got = {}
+    for cs in ("0", "1"):
+        monkeypatch.setenv("CVLM_GEMM_COLSPLIT", cs)
+        o = torch.full((M, N), float("nan"), device="cuda")
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=o, workspace=ws)
+        oh = hip.H2.empty(M, N + 64)                                  # a leading dimension wider than N, as lin1's output has
+        oh.t.fill_(float("nan"))
+        hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=1, out_h2=oh, ldoh=N + 64, ln_fold=(mrg, lin.colsum),
+                 workspace=ws)
+        torch.cuda.synchronize()
+        assert relerr(o.cpu().double(), ref) < 3e-6, cs
+        got[cs] = (o, oh.t.clone())
+    assert torch.equal(got["0"][0], got["1"][0])
+    assert torch.equal(got["0"][1][:, :, :N], got["1"][1][:, :, :N])
+    assert bool(torch.isnan(got["1"][1][:, :, N:]).all())                # nothing written beyond column N
+    z = F.gelu(F.layer_norm(xh.float().cpu().double()[:, :K] / XS, (K,), gamma.double(), beta.double(), 1e-6) @ w.double().t() + bias.double())
+    got_fold = (got["1"][1][0].float() + got["1"][1][1].float())[:, :N].cpu().double()
+    assert float((got_fold - z).abs().max()) < 2e-5 * max(1.0, float(z.abs().max()))
+    assert hip.gemm_workspace_errors(ws) == 0
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(581, 1024, 1024, "0"), (581, 1024, 4096, "4"), (300, 264, 96, "0"), (581, 3072, 1024, "0"),
                                        (130, 1024, 64, "0"), (581, 1024, 1024, "1")])
 def test_gemm_small_grid_ring_depth(hip, monkeypatch, M, N, K, sk):
