@@ -1107,14 +1107,30 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     static thread_local int in_colsplit = 0;
     static int colsplit_env = env_int("CVLM_GEMM_COLSPLIT", 1);
     if (live_env) colsplit_env = env_int("CVLM_GEMM_COLSPLIT", 1);
-    if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.M <= 4096 && !h2res && g.hm_S == 0 && g.ps_c2 == 0 &&
-        variant_env == 0) {
+    // CVLM_GEMM_COLSPLIT=2 (A/B): also for grids of several rounds whose last round is partial (proj / lin2 of a batch of 8:
+    // 128 x 5 = 640 tiles = 2.5 rounds): the columns whose tiles are whole rounds first, the rest (under one round) as the model
+    // picks; the h2-residual form included (residual planes and statistics pieces move with the column offset).
+    const bool cs_small = g.M <= 4096;
+    if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
+        (cs_small ? !h2res : colsplit_env >= 2)) {
         const int nby = (g.M + 255) / 256, nbx = (g.N + 255) / 256;
-        const int c0 = nby > 0 ? 256 / nby : 0;                          // column tiles of the first launch: one round of tiles
+        int c0 = 0;                                                      // column tiles of the first launch: whole rounds of tiles
+        bool ok = false;
+        if (cs_small) {
+            c0 = nby > 0 ? 256 / nby : 0;
+            const int rest_ = g.N - c0 * 256;
+            const long t1r = rest_ > 0 ? (long)((g.M + 127) / 128) * ((rest_ + 127) / 128) : 0;
+            ok = nbx > c0 && c0 * nby >= 232 && nbx * nby < 2 * 256 && rest_ >= 128 && t1r <= 256;
+        } else if ((long)nbx * nby % 256 != 0) {
+            for (int c = nbx - 1; c >= 1; --c)
+                if (((long)c * nby) % 256 == 0) { c0 = c; break; }
+            ok = c0 > 0 && (long)(nbx - c0) * nby <= 256 && (long)(nbx - c0) * nby >= 64;
+        }
         const int n0 = c0 * 256, rest = g.N - n0;
-        const long t1r = rest > 0 ? (long)((g.M + 127) / 128) * ((rest + 127) / 128) : 0;
-        if (nbx > c0 && c0 * nby >= 232 && nbx * nby < 2 * 256 && rest >= 128 && (rest & 7) == 0 && t1r <= 256 && (n0 & 7) == 0) {
+        if (ok && (rest & 7) == 0 && (n0 & 63) == 0) {
             cvlm_gemm_args a1 = g, a2 = g;
+            if (g.res_hi) { a2.res_hi = (const char*)g.res_hi + (int64_t)n0 * 2; a2.res_lo = (const char*)g.res_lo + (int64_t)n0 * 2; }
+            if (g.row_stats) a2.row_stats = g.row_stats + (int64_t)(n0 / 64) * g.M * 2;
             a1.N = n0;
             a2.N = rest;
             a2.w_hi = (const char*)g.w_hi + (int64_t)n0 * g.ldw * 2;

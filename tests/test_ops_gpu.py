@@ -164,6 +164,28 @@ def test_gemm_column_split_one_image(hip, monkeypatch, M, N, K):
     assert hip.gemm_workspace_errors(ws) == 0
 
 
+def test_gemm_column_split_partial_round_h2res(hip, monkeypatch):
+    """CVLM_GEMM_COLSPLIT=2: a grid of several rounds with a partial last one (32 x 10 tiles of 256^2 = 1.25 rounds) as whole rounds
+    + the remaining columns, h2-residual form: outputs, in-place residual and the statistics pieces carry the bits of the
+    single launch."""
+    M, N, K, XS = 8192, 2560, 256, 0.25
+    a, w, bias, res = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=K ** -0.5), rnd(N, seed=63), rnd(M, N, seed=64)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    ws = hip.new_gemm_workspace("cuda")
+    got = {}
+    for cs in ("1", "2"):
+        monkeypatch.setenv("CVLM_GEMM_COLSPLIT", cs)
+        o2 = hip.H2(hip.H2.pack(res * XS).t.cuda())
+        st_out = torch.full((hip.stats_pieces(N), M, 2), float("nan"), device="cuda")
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o2, residual_h2=(o2, 1.0 / XS), out_scale=XS, row_stats=st_out, workspace=ws)
+        torch.cuda.synchronize()
+        got[cs] = (o2.t.clone(), st_out)
+    assert torch.equal(got["1"][0], got["2"][0]) and torch.equal(got["1"][1], got["2"][1])
+    ref = A.float().cpu().double() @ W.float().cpu().double().t() + bias.double() + hip.H2.pack(res * XS).float().double() / XS
+    assert relerr((got["2"][0][0].float() + got["2"][0][1].float()).cpu().double() / XS, ref) < 3e-6
+    assert hip.gemm_workspace_errors(ws) == 0
+
+
 @pytest.mark.parametrize("M,N,K,sk", [(581, 1024, 1024, "0"), (581, 1024, 4096, "4"), (300, 264, 96, "0"), (581, 3072, 1024, "0"),
                                        (130, 1024, 64, "0"), (581, 1024, 1024, "1")])
 def test_gemm_small_grid_ring_depth(hip, monkeypatch, M, N, K, sk):
