@@ -293,7 +293,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                         const half2v h = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x, e.y));
                         ph[2 * p2] = h[0]; ph[2 * p2 + 1] = h[1];
                         if (SPV == 3) {
-                            const half2v l = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(e.x - (float)h[0], e.y - (float)h[1]));
+                            const half2v l = __builtin_bit_cast(half2v, split_lo_pk(__builtin_bit_cast(unsigned, h), e.x, e.y));
                             pl[2 * p2] = l[0]; pl[2 * p2 + 1] = l[1];
                         }
                     }

@@ -308,9 +308,8 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             const f32x2 v0 = z[p], v1 = z[4 + p];
             const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
             const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
-            const half2v f0 = __builtin_bit_cast(half2v, h0), f1 = __builtin_bit_cast(half2v, h1);
-            const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)f0[0], v0.y - (float)f0[1]));
-            const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)f1[0], v1.y - (float)f1[1]));
+            const unsigned l0 = split_lo_pk(h0, v0.x, v0.y);
+            const unsigned l1 = split_lo_pk(h1, v1.x, v1.y);
             const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
             const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
             xh[0][p] = (unsigned)rh[0]; xh[1][p] = (unsigned)rh[1];
@@ -693,9 +692,8 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                 const f32x2 v0 = z[e][p], v1 = z[e][4 + p];
                 const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
                 const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
-                const half2v f0 = __builtin_bit_cast(half2v, h0), f1 = __builtin_bit_cast(half2v, h1);
-                const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x - (float)f0[0], v0.y - (float)f0[1]));
-                const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x - (float)f1[0], v1.y - (float)f1[1]));
+                const unsigned l0 = split_lo_pk(h0, v0.x, v0.y);
+                const unsigned l1 = split_lo_pk(h1, v1.x, v1.y);
                 const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
                 const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
                 xh[e][0][p] = (unsigned)rh[0]; xh[e][1][p] = (unsigned)rh[1];

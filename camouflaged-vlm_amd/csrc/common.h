@@ -37,6 +37,20 @@ __device__ __forceinline__ void split_h2(float v, half_t& hi, half_t& lo) {
     lo = (half_t)(v - (float)hi);
 }
 
+// lo plane of two values whose hi plane is the fp16 pair packed in `h` (whatever rounding produced it): fp16(v - hi), ONE instruction
+// per value -- v_fma_mix reads the fp16 half of `h` and the f32 value in the same fused multiply-add, the f16 result lands in the
+// half of the destination it belongs to.  The softmax phases of the attention kernels split 32 probabilities per lane per 64 keys
+// this way; written as cvt + sub + pack it took 5-6 instructions per pair, 30 % of the phase's VALU work (global attention: 271 -> 223
+// VALU instructions per 64-key phase, 2.40 -> 2.37 ms per launch; lo is now rounded to nearest instead of truncated: cascade mask
+// error 5.0e-5 -> 3.9e-5).  The window kernels keep the cvt form: both this and the packed-convert form measured 1-3 % slower
+// there (256 VGPRs, one basic block scheduled around the MFMAs: profiles/r03_attn_split_lo_ab.log).
+__device__ __forceinline__ unsigned split_lo_pk(unsigned h, float vx, float vy) {
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(h), "v"(vx));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(h), "v"(vy));
+    return lo;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
