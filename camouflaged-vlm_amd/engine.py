@@ -11,6 +11,7 @@ f32 for residual streams and module outputs, h2 (split-half planes) for every GE
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -129,7 +130,6 @@ class LnLinear(Linear):
 def implicit_conv_ok(C: int) -> bool:
     """cvlm_gemm's implicit 3x3 convolution wants a power-of-two channel count >= 32 (include/cvlm.h, ABI 4); the tiny test
     geometries fall back to cvlm_im2col3x3 + GEMM.  CVLM_IMPLICIT_CONV=0 forces the fallback (A/B, tests)."""
-    import os
     return C >= 32 and (C & (C - 1)) == 0 and os.environ.get("CVLM_IMPLICIT_CONV", "1") == "1"
 
 
@@ -199,7 +199,6 @@ class SamEncoder(_Base):
         self.lin2cat = [Linear(torch.cat([sd[P + f"blocks.{i}.mlp.lin2.weight"].detach().float().cpu(), shw], 1),
                                sd[P + f"blocks.{i}.mlp.lin2.bias"].detach().float().cpu() + shb, device)
                         for i in range(g.depth - 1)]
-        import os
         # LayerNorm folded into the GEMMs that consume it + the residual stream kept in h2 between them: no LayerNorm
         # kernels inside the blocks (64 launches, 4.5 ms per step at B = 8).  CVLM_LN_FOLD=0 restores the separate passes.
         self.ln_fold = os.environ.get("CVLM_LN_FOLD", "1") == "1"
@@ -725,7 +724,6 @@ class ClipModel(_Base):
         self.vblocks = [block(f"{ie}transformer.resblocks.{i}.", False) for i in range(c.vision_layers)]
         # vision tower with ln_1 / ln_2 folded into in_proj / c_fc and the residual stream in h2 (as the SAM blocks, §4):
         # CVLM_CLIP_LN_FOLD=0 keeps the separate LayerNorm passes (the text tower, run once, always does)
-        import os
         self.ln_fold = os.environ.get("CVLM_CLIP_LN_FOLD", "1") == "1" and c.vision_width % 8 == 0
         if self.ln_fold:
             for i, blk in enumerate(self.vblocks):
@@ -905,7 +903,6 @@ class Cascade(_Base):
                       self.dev(sd["sam_visual_proj.2.weight"]), self.dev(sd["sam_visual_proj.2.bias"]))
         self.tproj = (self.dev(sd["sam_text_proj.0.weight"]), self.dev(sd["sam_text_proj.0.bias"]),
                       Linear(sd["sam_text_proj.1.weight"], sd["sam_text_proj.1.bias"], device))
-        import os
         # CLIP pass 1 runs on a side stream under the SAM encoder (+1.3 % at B = 8, same-box A/B).  CVLM_OVERLAP_CLIP=0
         # (bench.py --no-overlap) serialises it for profiling: co-running kernels stretch each other's durations,
         # which blurs per-kernel evidence.

@@ -8,3 +8,7 @@ python tools/summarize_profiles.py stats $O/stats $O/r03_dropin_b1_kernel_stats.
 python tools/kernel_gaps.py $O/stats tail:0.25 > $O/r03_dropin_b1_kernel_gaps.log 2>&1
 python tools/step_timeline.py $O/stats 16 > $O/r03_dropin_b1_step_timeline.log 2>&1
 rm -rf $O/stats
+# the same step with the CLIP pass issued first (rounds 1-2 order): the encoder's first kernel comes late
+CVLM_ENCODER_FIRST=0 rocprofv3 --kernel-trace --output-format csv -d $O/stats0 -- python3 bench.py --surface dropin --batch 1 --steps 16 --warmup 2 --no-cpu-baseline --no-roofline --no-power > $O/bench_stats0.log 2>&1
+python tools/step_timeline.py $O/stats0 16 > $O/r03_dropin_b1_step_timeline_clip_first.log 2>&1
+rm -rf $O/stats0

@@ -19,6 +19,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
     k = "gemm 256^2" if "gemm_nt_kernel<3, 2, 4, 5" in k else "gemm 256x128" if "gemm_nt_kernel<3, 4, 2, 3" in k else "gemm 128^2" if "gemm_nt_kernel<3, 2, 2, 2" in k \
+        else "gemm small-grid (deep ring, eight waves)" if "gemm_nt_kernel<3, 4, 2, 14" in k \
         else "attn global" if "g64pair" in k else "attn window" if "attn_win14" in k else "attn clip" if "attn_kernel" in k else None
     if k is None: continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -36,4 +37,8 @@ rm -rf $O/stats $O/fetch $O/write $O/sq
 python tools/gemm_shapes.py --batch 8 --reps 2 --pipelined > $O/r03_per_shape_times.log 2>&1
 python bench.py --workload encoder --steps 8 --warmup 2 > $O/r03_bench_encoder_b8.json 2> $O/enc.err; tail -c 600 $O/r03_bench_encoder_b8.json
 python bench.py --geometry hires1536 --batch 4 --workload encoder --steps 6 --warmup 2 > $O/r03_bench_hires1536_b4.json 2> $O/hires.err; tail -c 600 $O/r03_bench_hires1536_b4.json
+python bench.py --surface dropin --batch 1 --steps 32 --no-cpu-baseline > $O/r03_bench_dropin_b1.json 2> $O/dropin_b1.err; tail -c 300 $O/r03_bench_dropin_b1.json
+python bench.py --surface dropin --batch 8 --steps 10 --no-cpu-baseline > $O/r03_bench_dropin_b8.json 2> $O/dropin_b8.err; tail -c 300 $O/r03_bench_dropin_b8.json
+python tools/gemm_shapes.py --batch 1 --reps 4 > $O/r03_per_shape_times_b1.log 2>&1
+BATCH=1 python tools/graph_step.py > $O/r03_hipgraph_b1.log 2>&1
 ls -la $O
