@@ -245,10 +245,20 @@ class SamEncoder(_Base):
                  stride_w=2 * N * N, stride_r=N * N, stride_o=N * N, split=sp)
         return out
 
-    def forward(self, inp: torch.Tensor, taps: Optional[dict] = None, out_name: str = "features") -> torch.Tensor:
+    # blocks whose launches the host issues before it runs `issue_hook` (Cascade: the side stream's CLIP launches)
+    HOOK_AFTER_BLOCKS = 5
+
+    def _hook(self, i: int) -> None:
+        """Called after the launches of block i: runs the caller's issue hook once enough of the encoder is queued."""
+        if self._issue_hook is not None and i + 1 >= min(self.HOOK_AFTER_BLOCKS, self.g.depth):
+            hook, self._issue_hook = self._issue_hook, None
+            hook()
+
+    def forward(self, inp: torch.Tensor, taps: Optional[dict] = None, out_name: str = "features", issue_hook=None) -> torch.Tensor:
         """inp (B,3,S,S) f32 on device -> features f32 [B*G*G][out_chans] (token-major NHWC), in workspace buffer
         `out_name` (a caller that keeps two batches in flight alternates two names)."""
         self._out_name = out_name
+        self._issue_hook = issue_hook
         g, ws, pr = self.g, self.ws, self.prec
         B = inp.shape[0]
         assert inp.shape[1:] == (3, g.inp_size, g.inp_size), \
@@ -316,6 +326,7 @@ class SamEncoder(_Base):
                 self.gemm(hid, blk["lin2"], M, lda=HK, residual=x, out_f32=x, alpha=1.0 / HID_SCALE)
             if taps is not None:
                 taps[f"block{i}"] = x.clone()
+            self._hook(i)
         hip.add_rows(x, None, 1, M, D, scale=X_SCALE, out_h2=xn)
         return self._neck(xn, B)
 
@@ -358,6 +369,7 @@ class SamEncoder(_Base):
             else:
                 self.gemm(hid, blk["lin2"], M, lda=HK, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
                           alpha=1.0 / HID_SCALE)
+            self._hook(i)
         return self._neck(xh, B)
 
     def _neck(self, xn: H2, B: int) -> torch.Tensor:
@@ -947,15 +959,22 @@ class Cascade(_Base):
                 self._side = torch.cuda.Stream(device=self.device)
             main = torch.cuda.current_stream()
             if self.encoder_first:
-                # the host issues the ENCODER's launches first: one image's CLIP pass is ~190 launches of a few workgroups each, the
-                # GPU runs them as fast as the host can issue them, and an encoder issued behind them started 4 ms late with the
-                # chip nearly idle until then (tools/step_timeline.py).  The side stream waits for the inputs, not for the encoder.
+                # the host issues the ENCODER's first blocks before the CLIP pass: one image's pass is ~190 launches of a few
+                # workgroups each, the GPU runs them as fast as the host can issue them, and an encoder issued behind them started
+                # 4 ms late with the chip nearly idle until then (tools/step_timeline.py).  Five blocks (3 ms of GPU work for one
+                # image) are queued first, then the pass, then the rest: a slow host (a profiler, a loaded node) does not push the
+                # pass behind ALL of the encoder's launches either.  The side stream waits for the inputs, not for the encoder.
                 ready = torch.cuda.Event()
                 ready.record(main)
-                feats = self.encoder.forward(inp, taps)
-                self._side.wait_event(ready)
-                with torch.cuda.stream(self._side):
-                    img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
+                res = []
+
+                def issue_clip():
+                    self._side.wait_event(ready)
+                    with torch.cuda.stream(self._side):
+                        res.append(self.clip.forward(clip_image, clip_mask))
+
+                feats = self.encoder.forward(inp, taps, issue_hook=issue_clip)
+                img_f, txt_f, pred, score = res[0]
             else:
                 self._side.wait_stream(main)
                 with torch.cuda.stream(self._side):
@@ -1006,12 +1025,17 @@ class Cascade(_Base):
         if self.encoder_first:                                       # see infer_test
             ready = torch.cuda.Event()
             ready.record(main)
-            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+            res = []
+
+            def issue_clip():
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    res.append(self.clip.forward(clip_image, clip_mask))
+
+            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity, issue_hook=issue_clip)
             enc_done = torch.cuda.Event()
             enc_done.record(main)
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
+            img_f, txt_f, _, _ = res[0]
         else:
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -1070,12 +1094,17 @@ class Cascade(_Base):
         if self.encoder_first and side is not main:                  # see infer_test
             ready = torch.cuda.Event()
             ready.record(main)
-            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
+            res = []
+
+            def issue_clip():
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    res.append(clip_forwards())
+
+            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity, issue_hook=issue_clip)
             enc_done = torch.cuda.Event()
             enc_done.record(main)
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                img_f, txt_f = clip_forwards()
+            img_f, txt_f = res[0]
         else:
             side.wait_stream(main)
             with torch.cuda.stream(side):
