@@ -67,9 +67,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // stores its fp32 accumulators as a slab in the workspace and counts itself in; the part that arrives LAST (an atomic counter,
 // no polling: safe whatever else shares the chip) adds the slabs of all parts in index order -- its own included, read back
 // like the others, so the order of the fp32 additions does not depend on who was last -- and runs the epilogue.
+// WIL (ABI 6, cvlm_gemm_args.w_il): the weight operand is staged from the image whose planes are interleaved per 32 k-elements --
+// a weight row's K-tile is ONE 128-byte line (hi 64 B | lo 64 B), a DMA instruction covers 8 rows x 128 bytes instead of 16 rows x 64
+// bytes of one plane, and every L2 line is requested once instead of once per half.  In LDS the weight region becomes [BN rows][128
+// bytes], 16-byte chunks of row r permuted by ^ ((r >> 1) & 7) (the conflict-free image of the 128-byte-row loop); chunks 0-3 of a
+// row are the hi plane's k 0-31, chunks 4-7 the lo plane's.  Same fragments, same MFMAs, same bits.
 template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1, bool CONV = false,
-          bool SK = false>
+          bool SK = false, bool WIL = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
+    static_assert(!WIL || (SPLIT == 3 && BK == 32 && !CONV && NSTAGE != 4 && NSTAGE != 6), "interleaved weights: split-3 kernels with 32-wide K-tiles");
     static_assert(!SK || (!PERSIST && !CONV && NSTAGE != 5), "split-K form: plain tile loops only");
     static_assert(!PERSIST || NSTAGE == 5, "persistent form exists for the staggered 256^2 loop only");
     static_assert(!CONV || (NSTAGE == 2 && BK == 32), "implicit 3x3 convolution: 2-stage loop, 32-wide K-tiles");
@@ -98,13 +104,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     const int z = blockIdx.y;
     const half_t* Ahi = (const half_t*)g.a_hi + (int64_t)z * g.stride_a;
     const half_t* Alo = (const half_t*)g.a_lo + (int64_t)z * g.stride_a;
-    const half_t* Whi = (const half_t*)g.w_hi + (int64_t)z * g.stride_w;
+    const half_t* Whi = WIL ? (const half_t*)g.w_il : (const half_t*)g.w_hi + (int64_t)z * g.stride_w;
     const half_t* Wlo = (const half_t*)g.w_lo + (int64_t)z * g.stride_w;
 
     // ---- per-tile state (set_tile): coordinates, K range, DMA source of every staging instruction of this wave
     int bm = 0, bn = 0, kpart = 0, kparts = 1, tail_j = 0, nk = 0;
     const half_t* src[PER_WAVE];
     int dst_off[PER_WAVE];                                            // stage layout: [Ahi][Alo][Whi][Wlo]; instruction i covers 16 rows x 64 B
+    // WIL: K advance of staging instruction j in halves per K-tile element -- weight instructions walk the interleaved image, where a
+    // K-tile is 64 halves (hi | lo) of a row; the instruction index is wave-uniform, so this is scalar arithmetic
+    auto kmul = [&](int j) -> int { return (WIL && wave * PER_WAVE + j >= NPA * A_INSTR) ? 2 : 1; };
     [[maybe_unused]] int tapmask[PER_WAVE];                           // CONV: bit t = tap t of this lane's row lies inside the image; bit 9 = weight row
     // Everything a run-time ?: selects between comes in as a parameter or is a local of the body: a conditional between two
     // by-reference captures becomes a run-time index into the closure, which pins it -- and every capture -- in scratch.
@@ -149,6 +158,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         for (int j = 0; j < PER_WAVE; ++j) {
             const int i = wave * PER_WAVE + j;
             const bool isW = i >= NPA * A_INSTR;
+            if (WIL && isW) {                                             // 8 rows x 128 bytes of the interleaved image
+                const int ii2 = i - NPA * A_INSTR;
+                const int row8 = ii2 * 8 + (lane >> 3), pos8 = lane & 7;
+                int grow8 = bn_ + row8;
+                grow8 = grow8 < N_ - 1 ? grow8 : N_ - 1;
+                src[j] = whi + (int64_t)grow8 * ldw_ + ((pos8 ^ ((row8 >> 1) & 7)) * 8);
+                dst_off[j] = NPA * A_PLANE + ii2 * 1024;
+                continue;
+            }
             const int ii = isW ? i - NPA * A_INSTR : i;
             const int per = isW ? W_INSTR : A_INSTR;
             const int plane = ii / per, sub = ii - plane * per;
@@ -179,10 +197,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             const int k0 = kpart * base + (kpart < extra ? kpart : extra);
             nk = base + (kpart < extra ? 1 : 0);
 #pragma unroll
-            for (int j = 0; j < PER_WAVE; ++j) src[j] += (int64_t)k0 * BK;
+            for (int j = 0; j < PER_WAVE; ++j) src[j] += (int64_t)k0 * BK * kmul(j);
         }
     };
-    auto set_tile = [&](int pid) { set_tile_(pid, Ahi, Alo, Whi, Wlo, g.lda, g.ldw, g.M, g.N); };
+    auto set_tile = [&](int pid) { set_tile_(pid, Ahi, Alo, Whi, Wlo, g.lda, WIL ? g.ldw_il : g.ldw, g.M, g.N); };
     int vblk = blockIdx.x;
     set_tile(vblk);
 
@@ -193,13 +211,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     auto chunk_off = [&](int ks) -> int {               // byte offset of this lane's 16-B chunk of k-step ks
         return (BK == 32) ? ((fq ^ swz4((fr >> 2) & 3)) * 16) : (((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16);
     };
+    // weight fragment i (16 rows) of plane pl from the stage at `cur` (byte address); `co` = chunk_off of the k-step
+    auto w_frag = [&](const unsigned char* cur, int i, int pl, int co) -> half8 {
+        if (WIL) return *(const half8*)(cur + NPA * A_PLANE + (wn * 64 + fr + i * 16) * 128 + (((4 * pl + fq) ^ ((fr >> 1) & 7)) * 16));
+        return *(const half8*)(cur + NPA * A_PLANE + pl * W_PLANE + w_row + i * 16 * ROWB + co);
+    };
 
     floatx4 acc[MT][4];
     // DMA source of staging instruction j for K-tile t.  CONV: K-tile t lies in tap t / (C / 32) (C a power of two), channels
     // from (t % (C / 32)) * 32; the tap moves the pixel by (dy, dx), i.e. the address by a wave-uniform offset.
     const int conv_lc = CONV ? 31 - __builtin_clz((unsigned)(g.conv_c / BK)) : 0;
     auto src_at = [&](int j, int t) -> const void* {
-        if (!CONV) return src[j] + (int64_t)t * BK;
+        if (!CONV) return src[j] + (int64_t)t * BK * kmul(j);
         const int tap = t >> conv_lc, c0 = (t - (tap << conv_lc)) * BK;
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;                            // tap / 3, tap % 3 for tap in 0..8
         const int64_t off = (int64_t)((ky - 1) * g.conv_w + (kx - 1)) * g.conv_c + c0;
@@ -226,8 +249,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         const unsigned char* cur = smem + slot * STAGE;
         const unsigned char* pAhi = cur;
         const unsigned char* pAlo = cur + A_PLANE;
-        const unsigned char* pWhi = cur + NPA * A_PLANE;
-        const unsigned char* pWlo = pWhi + W_PLANE;
         const bool dma = tn >= 0 && !(DBG == 1 && tn > 1);
         unsigned char* nxt = smem + sn * STAGE;
 #pragma unroll
@@ -236,8 +257,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             half8 wh[4], wl[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                wh[i] = *(const half8*)(pWhi + w_row + i * 16 * ROWB + co);
-                if (SPLIT == 3) wl[i] = *(const half8*)(pWlo + w_row + i * 16 * ROWB + co);
+                wh[i] = w_frag(cur, i, 0, co);
+                if (SPLIT == 3) wl[i] = w_frag(cur, i, 1, co);
             }
 #pragma unroll
             for (int mh = 0; mh < MT / MG; ++mh) {                  // 4 m-tiles at a time keeps fragments at 64 VGPRs
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     constexpr int PP = PER_WAVE / 4;
 #pragma unroll
                     for (int j = (mt - 1) * PP; j < (mt == 4 ? PER_WAVE : mt * PP); ++j)
-                        glds16(src[j] + koff, nxt + dst_off[j]);
+                        glds16(src[j] + koff * kmul(j), nxt + dst_off[j]);
                 }
             }
             // tile t+1 (issued one iteration ago) must have landed for every wave; tile t+2 may stay in flight
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     constexpr int PP = (PER_WAVE + 3) / 4;
 #pragma unroll
                     for (int j = (mt - 1) * PP; j < (mt * PP < PER_WAVE ? mt * PP : PER_WAVE); ++j)
-                        glds16(src[j] + koff, smem + dst_off[j]);
+                        glds16(src[j] + koff * kmul(j), smem + dst_off[j]);
                 }
             }
             wait_vmcnt<0>();                                             // tile t+1 landed (this wave's share)
@@ -436,7 +457,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 if (dma) {                                        // this wave's DMA pieces, spread over the MFMA groups of the phase
 #pragma unroll
                     for (int j = (mt * PER_WAVE) / MH; j < ((mt + 1) * PER_WAVE) / MH; ++j)
-                        glds16(src[j] + koff, nxt + dst_off[j]);
+                        glds16(src[j] + koff * kmul(j), nxt + dst_off[j]);
                 }
             }
         };
@@ -448,11 +469,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             }
         };
         auto read_w = [&](const unsigned char* cur) {
-            const unsigned char* pWhi = cur + NPA * A_PLANE;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                wh[i] = *(const half8*)(pWhi + w_row + i * 16 * ROWB + co);
-                if (SPLIT == 3) wl[i] = *(const half8*)(pWhi + W_PLANE + w_row + i * 16 * ROWB + co);
+                wh[i] = w_frag(cur, i, 0, co);
+                if (SPLIT == 3) wl[i] = w_frag(cur, i, 1, co);
             }
         };
         // prologue: tile 0 resident for everyone; group B also launches its share of tile 1 (its "P1(-1)").
@@ -1135,6 +1155,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             a2.N = rest;
             a2.w_hi = (const char*)g.w_hi + (int64_t)n0 * g.ldw * 2;
             if (g.w_lo) a2.w_lo = (const char*)g.w_lo + (int64_t)n0 * g.ldw * 2;
+            if (g.w_il) a2.w_il = (const char*)g.w_il + (int64_t)n0 * g.ldw_il * 2;
             if (g.bias) a2.bias = g.bias + n0;
             if (g.ln_colsum) a2.ln_colsum = g.ln_colsum + n0;
             if (g.residual) a2.residual = g.residual + n0;
@@ -1157,6 +1178,10 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     p.total_blocks = 0;
     const bool have_ws = g.workspace && g.workspace_bytes >= cvlm_gemm_workspace_bytes();
     hipStream_t s = (hipStream_t)stream;
+    // interleaved weight image (ABI 6): used by the big-tile kernels when the caller provides it (CVLM_GEMM_WIL=0: never)
+    static int wil_env = env_int("CVLM_GEMM_WIL", 1);
+    if (live_env) wil_env = env_int("CVLM_GEMM_WIL", 1);
+    const bool wil = wil_env && g.w_il && g.split == 3 && !conv && p.a.batch == 1 && g.ldw_il >= 2 * (int64_t)g.K && (g.ldw_il & 7) == 0;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
     int variant = variant_env;
     if (variant == 0) {
@@ -1321,10 +1346,13 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         constexpr int smem_ = 2 * 2 * (256 + 256) * 32 * 2;                                                        \
         p.nbx = (g.N + 255) / 256; p.nby = (g.M + 255) / 256;                                                      \
         auto kern_ = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, false, EPI_>;                                            \
+        auto kernw_ = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, false, EPI_, false, false, true>;                       \
         static bool attr_[16] = {};                                                                                \
-        if (cvlm_first_on_device(attr_))                                                                           \
+        if (cvlm_first_on_device(attr_)) {                                                                         \
             (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);     \
-        hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby + extra_blocks, 1), dim3(512), smem_, s, p);                   \
+            (void)hipFuncSetAttribute((const void*)kernw_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);    \
+        }                                                                                                          \
+        hipLaunchKernelGGL(wil ? kernw_ : kern_, dim3(p.nbx* p.nby + extra_blocks, 1), dim3(512), smem_, s, p);    \
     } while (0)
     int extra_blocks = 0;
     if (conv) {
@@ -1376,10 +1404,13 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
                 constexpr int smem6 = 2 * 2 * (192 + 256) * 32 * 2;
                 p.nbx = (g.N + 255) / 256; p.nby = (g.M + 191) / 192;
                 auto k6 = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 6, false, 2>;
+                auto k6w = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 6, false, 2, false, false, true>;
                 static bool attr6[16] = {};
-                if (cvlm_first_on_device(attr6))
+                if (cvlm_first_on_device(attr6)) {
                     (void)hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, smem6);
-                hipLaunchKernelGGL(k6, dim3(p.nbx * p.nby, 1), dim3(512), smem6, s, p);
+                    (void)hipFuncSetAttribute((const void*)k6w, hipFuncAttributeMaxDynamicSharedMemorySize, smem6);
+                }
+                hipLaunchKernelGGL(wil ? k6w : k6, dim3(p.nbx * p.nby, 1), dim3(512), smem6, s, p);
                 CVLM_CHECK_LAUNCH();
                 return 0;
             }
@@ -1399,10 +1430,13 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #define CVLM_LAUNCH_P(EPI_)                                                                                        \
     do {                                                                                                           \
         auto kp = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true, EPI_>;                                                \
+        auto kpw = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true, EPI_, false, false, true>;                           \
         static bool attr_p[16] = {};                                                                               \
-        if (cvlm_first_on_device(attr_p))                                                                          \
+        if (cvlm_first_on_device(attr_p)) {                                                                        \
             (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);       \
-        hipLaunchKernelGGL(kp, dim3(cus, 1), dim3(512), smem_p, s, p);                                             \
+            (void)hipFuncSetAttribute((const void*)kpw, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);      \
+        }                                                                                                          \
+        hipLaunchKernelGGL(wil ? kpw : kp, dim3(cus, 1), dim3(512), smem_p, s, p);                                 \
     } while (0)
                 if (fold) CVLM_LAUNCH_P(1); else if (h2res) CVLM_LAUNCH_P(2); else CVLM_LAUNCH_P(0);
 #undef CVLM_LAUNCH_P
@@ -1410,7 +1444,16 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
                 return 0;
             }
         }
-        if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
+        if (variant == 2 && wil) {                                           /* 256 x 128 tiles, weight from the interleaved image */
+            constexpr int smem2 = 3 * 2 * (256 + 128) * 32 * 2;
+            p.nbx = (g.N + 127) / 128; p.nby = (g.M + 255) / 256;
+            auto k2w = gemm_nt_kernel<3, 4, 2, 3, 32, 0, 4, false, -1, false, false, true>;
+            static bool attr2[16] = {};
+            if (cvlm_first_on_device(attr2))
+                (void)hipFuncSetAttribute((const void*)k2w, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+            hipLaunchKernelGGL(k2w, dim3(p.nbx * p.nby, 1), dim3(512), smem2, s, p);
+        }
+        else if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
         else if (variant == 7 && lds_staged && p.a.batch == 1) {             /* 256x256, 8 waves, wave groups staggered; one epilogue form */
             if (fold) CVLM_LAUNCH_E(1); else if (h2res) CVLM_LAUNCH_E(2); else CVLM_LAUNCH_E(0);
         }

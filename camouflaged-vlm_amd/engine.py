@@ -107,6 +107,9 @@ class Linear:
         e = max(min(e, 24), -24)
         self.alpha = float(2.0 ** (-e))
         self.w = H2(H2.pack(wp * (2.0 ** e)).t.to(device))
+        # second image with the planes interleaved per 32 k-elements (cvlm_gemm_args.w_il, ABI 6): what the big-tile kernels stage
+        # the weight from; small matrices never reach those kernels
+        self.w_il = hip.interleave_planes(self.w) if self.N * self.K >= (1 << 18) and os.environ.get("CVLM_GEMM_WIL", "1") == "1" else None
         self.bias = None
         if b is not None:
             bp = torch.zeros(self.N)
@@ -145,8 +148,9 @@ class _Base:
         alpha = kw.pop("alpha", 1.0)
         if "bias" not in kw:
             kw["bias"] = lin.bias
+        w_il = lin.w_il if kw.get("batch", 1) == 1 and kw.get("conv3x3") is None and "ldw" not in kw else None
         hip.gemm(a, lin.w, M, kw.pop("N", lin.N), lin.K, alpha=alpha * lin.alpha,
-                 workspace=self.ws.gemm_ws() if self.ksplit else None, **kw)
+                 workspace=self.ws.gemm_ws() if self.ksplit else None, w_il=w_il, **kw)
 
     def attention(self, qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, **kw) -> None:
         hip.attention(qkv, out, B, S, heads, hd,

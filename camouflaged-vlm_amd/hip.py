@@ -26,7 +26,7 @@ EXPORTS = [
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
     "cvlm_ln_stats_merge",
 ]
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GemmArgs(C.Structure):
@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
         ("res_hi", C.c_void_p), ("res_lo", C.c_void_p), ("ldrh", C.c_int64), ("res_scale", C.c_float),
         ("row_stats", C.c_void_p),
         ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_c", C.c_int32),
+        ("w_il", C.c_void_p), ("ldw_il", C.c_int64),
     ]
 
 
@@ -122,6 +123,14 @@ def gemm_workspace_errors(ws: torch.Tensor) -> int:
     return int(words[0]) + int(words[1])
 
 
+def interleave_planes(w: "H2") -> torch.Tensor:
+    """[2][N][K] planes -> fp16 [N][2K] with row n = (hi k0..31 | lo k0..31 | hi k32..63 | lo k32..63 | ...): the `w_il` image of
+    cvlm_gemm (include/cvlm.h, ABI 6).  K % 32 == 0."""
+    two, N, K = w.t.shape
+    assert two == 2 and K % 32 == 0
+    return w.t.reshape(2, N, K // 32, 32).permute(1, 2, 0, 3).reshape(N, 2 * K).contiguous()
+
+
 class H2:
     """Split-half tensor: two fp16 planes stored as one (2, *shape) fp16 tensor."""
 
@@ -176,8 +185,11 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          workspace: Optional[torch.Tensor] = None,
          ln_fold: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          residual_h2: Optional[Tuple["H2", float]] = None, ldrh: Optional[int] = None,
-         row_stats: Optional[torch.Tensor] = None, conv3x3: Optional[Tuple[int, int, int]] = None) -> None:
-    """conv3x3 = (H, W, C): `a` is an NHWC image [B*H*W][C] and K = 9*C runs over the taps of a 3x3 / pad 1 convolution
+         row_stats: Optional[torch.Tensor] = None, conv3x3: Optional[Tuple[int, int, int]] = None,
+         w_il: Optional[torch.Tensor] = None) -> None:
+    """w_il: the same weight with its planes interleaved per 32 k-elements (`interleave_planes(w)`, ABI 6): the big-tile kernels stage
+    the weight from it (whole 128-byte lines per row and K-tile), same bits.
+    conv3x3 = (H, W, C): `a` is an NHWC image [B*H*W][C] and K = 9*C runs over the taps of a 3x3 / pad 1 convolution
     (implicit GEMM: the im2col gather happens in the DMA addresses).
     ln_fold = (merged [M][2] f32 = (rstd, mu * rstd) from ln_stats_merge, colsum [N] f32): LayerNorm of the input folded into this
     GEMM (include/cvlm.h);
@@ -187,6 +199,9 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     g = GemmArgs()
     g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
     g.w_hi, g.w_lo, g.ldw, g.stride_w = w.hi.data_ptr(), w.lo.data_ptr(), ldw if ldw is not None else K, stride_w
+    if w_il is not None:
+        assert w_il.dtype == torch.float16 and w_il.dim() == 2 and w_il.shape[1] >= 2 * K and w_il.is_contiguous() and batch == 1
+        g.w_il, g.ldw_il = w_il.data_ptr(), w_il.shape[1]
     g.bias = _p(bias)
     g.residual, g.ldr, g.stride_r = _p(residual), (ldr if ldr is not None else N), stride_r
     g.out_f32, g.ldo, g.stride_o = _p(out_f32), (ldo if ldo is not None else N), stride_o

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 5
+#define CVLM_ABI_VERSION 6
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -95,6 +95,14 @@ typedef struct cvlm_gemm_args {
      * addresses and a tap outside the image reads zeros.  conv_c a power of two >= 32, one problem per launch.
      * Replaces the 3x3 convolutions of image_encoder.py:150 (neck) and mask_decoder_edge.py:88-93 (edge feature head). */
     int32_t conv_h, conv_w, conv_c;
+    /* ABI 6 -- optional second image of the SAME weight with its planes interleaved per 32 k-elements:
+     *     w_il[n][k / 32][plane][k % 32]   (fp16; plane 0 = hi, 1 = lo; row n starts at w_il + n * ldw_il, ldw_il >= 2 * K halves)
+     * so that the 64 bytes of hi and the 64 bytes of lo a K-tile needs from a weight row are ONE 128-byte line.  The big-tile kernels
+     * stage the weight operand from this image when it is given (8 rows x 128 bytes per DMA instruction instead of 16 rows x 64
+     * bytes: every L2 line is requested once, not once per plane-half -- 1.4 % of the GEMM's energy at the power cap,
+     * profiles/r03_wil_ab.log); the other kernels, and every kernel when it is NULL, read w_hi / w_lo.  Same bits either way.
+     * NULL for batched launches and implicit convolutions. */
+    const void* w_il; int64_t ldw_il;
 } cvlm_gemm_args;
 int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
 int64_t cvlm_gemm_workspace_bytes(void);

@@ -164,6 +164,51 @@ def test_gemm_column_split_one_image(hip, monkeypatch, M, N, K):
     assert hip.gemm_workspace_errors(ws) == 0
 
 
+@pytest.mark.parametrize("M,N,K,variant,use_ws", [(16640, 1280, 256, "7", False),      # 325 tiles: persistent 256^2 kernel
+                                                   (8192, 1280, 320, "7", True),        # 160 tiles: one-pass 256^2 kernel
+                                                   (9296, 1024, 512, "0", True),        # 192-row tiles (h2-residual form), 256^2 otherwise
+                                                   (8200, 1160, 256, "2", True),        # 256 x 128 tiles, ragged M / N
+                                                   (4096, 5120, 256, "0", True)])       # one image's lin1: column split + interleaved
+def test_gemm_interleaved_weights_same_bits(hip, monkeypatch, M, N, K, variant, use_ws):
+    """ABI 6: the big-tile kernels stage the weight from the image whose planes are interleaved per 32 k-elements (whole 128-byte
+    lines).  Same fragments, same MFMA order: plain, LayerNorm-folded and h2-residual launches give the bits of the planar launch."""
+    from camouflaged_vlm_amd.engine import LnLinear
+    monkeypatch.setenv("CVLM_GEMM_VARIANT", variant)
+    a, w, bias, res = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=K ** -0.5), rnd(N, seed=73), rnd(M, N, seed=74)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    Wil = hip.interleave_planes(W)
+    assert Wil.shape == (N, 2 * K) and torch.equal(Wil[5, 32:64], W.lo[5, 0:32]) and torch.equal(Wil[5, 64:96], W.hi[5, 32:64])
+    ws = hip.new_gemm_workspace("cuda") if use_ws else None
+    XS = 0.25
+    x = rnd(M, K, seed=75) * 2.0
+    gamma, beta = 1.0 + 0.1 * rnd(K, seed=76), 0.05 * rnd(K, seed=77)
+    xh, st, mrg = hip.H2.empty(M, K), torch.empty(hip.stats_pieces(K), M, 2, device="cuda"), torch.empty(M, 2, device="cuda")
+    hip.row_stats_split(x.cuda(), XS, xh, st, M, K)
+    hip.ln_stats_merge(st, M, K, 1e-6, mrg, hip.new_gemm_workspace("cuda"))
+    lin = LnLinear(w, bias, gamma, beta, "cuda")
+    lin_il = hip.interleave_planes(lin.w)
+    got = {}
+    for tag, wil, lil in (("planar", None, None), ("interleaved", Wil, lin_il)):
+        o = torch.full((M, N), float("nan"), device="cuda")
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_f32=o, workspace=ws, w_il=wil)
+        oh = hip.H2.empty(M, N)
+        oh.t.fill_(float("nan"))
+        hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=1, out_h2=oh, ln_fold=(mrg, lin.colsum), workspace=ws,
+                 w_il=lil)
+        o2 = hip.H2(hip.H2.pack(res * XS).t.cuda())
+        st_out = torch.full((hip.stats_pieces(N), M, 2), float("nan"), device="cuda")
+        hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o2, residual_h2=(o2, 1.0 / XS), out_scale=XS, row_stats=st_out, workspace=ws,
+                 w_il=wil)
+        torch.cuda.synchronize()
+        got[tag] = (o, oh.t.clone(), o2.t.clone(), st_out)
+    ref = A.float().cpu().double() @ W.float().cpu().double().t() + bias.double()
+    assert relerr(got["interleaved"][0].cpu().double(), ref) < 3e-6
+    for i in range(4):
+        assert torch.equal(got["planar"][i], got["interleaved"][i]), i
+    if ws is not None:
+        assert hip.gemm_workspace_errors(ws) == 0
+
+
 def test_gemm_column_split_partial_round_h2res(hip, monkeypatch):
     """CVLM_GEMM_COLSPLIT=2: a grid of several rounds with a partial last one (32 x 10 tiles of 256^2 = 1.25 rounds) as whole rounds
     + the remaining columns, h2-residual form: outputs, in-place residual and the statistics pieces carry the bits of the
