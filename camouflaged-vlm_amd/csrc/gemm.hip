@@ -73,9 +73,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // bytes], 16-byte chunks of row r permuted by ^ ((r >> 1) & 7) (the conflict-free image of the 128-byte-row loop); chunks 0-3 of a
 // row are the hi plane's k 0-31, chunks 4-7 the lo plane's.  Same fragments, same MFMAs, same bits.
 template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1, bool CONV = false,
-          bool SK = false, bool WIL = false>
+          bool SK = false, bool WIL = false, bool AIL = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
     static_assert(!WIL || (SPLIT == 3 && BK == 32 && !CONV && NSTAGE != 4 && NSTAGE != 6), "interleaved weights: split-3 kernels with 32-wide K-tiles");
+    // AIL (cvlm_gemm_args.a_il): the same for the ACTIVATION operand -- a_hi is an image [M][K / 32][plane][32] (what an out_il launch
+    // or cvlm_row_stats_split with il wrote), lda its row stride in halves; LDS region [BM rows][128 bytes], same chunk permutation.
+    static_assert(!AIL || WIL, "interleaved activations come with interleaved weights (one set of instantiations)");
     static_assert(!SK || (!PERSIST && !CONV && NSTAGE != 5), "split-K form: plain tile loops only");
     static_assert(!PERSIST || NSTAGE == 5, "persistent form exists for the staggered 256^2 loop only");
     static_assert(!CONV || (NSTAGE == 2 && BK == 32), "implicit 3x3 convolution: 2-stage loop, 32-wide K-tiles");
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     int dst_off[PER_WAVE];                                            // stage layout: [Ahi][Alo][Whi][Wlo]; instruction i covers 16 rows x 64 B
     // WIL: K advance of staging instruction j in halves per K-tile element -- weight instructions walk the interleaved image, where a
     // K-tile is 64 halves (hi | lo) of a row; the instruction index is wave-uniform, so this is scalar arithmetic
-    auto kmul = [&](int j) -> int { return (WIL && wave * PER_WAVE + j >= NPA * A_INSTR) ? 2 : 1; };
+    auto kmul = [&](int j) -> int { return (wave * PER_WAVE + j >= NPA * A_INSTR ? WIL : AIL) ? 2 : 1; };
     [[maybe_unused]] int tapmask[PER_WAVE];                           // CONV: bit t = tap t of this lane's row lies inside the image; bit 9 = weight row
     // Everything a run-time ?: selects between comes in as a parameter or is a local of the body: a conditional between two
     // by-reference captures becomes a run-time index into the closure, which pins it -- and every capture -- in scratch.
@@ -158,6 +161,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         for (int j = 0; j < PER_WAVE; ++j) {
             const int i = wave * PER_WAVE + j;
             const bool isW = i >= NPA * A_INSTR;
+            if (AIL && !isW) {                                            // activations: 8 rows x 128 bytes of the interleaved image
+                const int row8 = i * 8 + (lane >> 3), pos8 = lane & 7;
+                int grow8 = bm_ + row8;
+                grow8 = grow8 < M_ - 1 ? grow8 : M_ - 1;
+                src[j] = ahi + (int64_t)grow8 * lda_ + ((pos8 ^ ((row8 >> 1) & 7)) * 8);
+                dst_off[j] = i * 1024;
+                continue;
+            }
             if (WIL && isW) {                                             // 8 rows x 128 bytes of the interleaved image
                 const int ii2 = i - NPA * A_INSTR;
                 const int row8 = ii2 * 8 + (lane >> 3), pos8 = lane & 7;
@@ -211,6 +222,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     auto chunk_off = [&](int ks) -> int {               // byte offset of this lane's 16-B chunk of k-step ks
         return (BK == 32) ? ((fq ^ swz4((fr >> 2) & 3)) * 16) : (((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16);
     };
+    // activation fragment of m-tile mt, plane pl
+    auto a_frag = [&](const unsigned char* cur, int mt, int pl, int co) -> half8 {
+        if (AIL) return *(const half8*)(cur + (wm * WROWS + fr + mt * 16) * 128 + (((4 * pl + fq) ^ ((fr >> 1) & 7)) * 16));
+        return *(const half8*)(cur + pl * A_PLANE + a_row + mt * 16 * ROWB + co);
+    };
     // weight fragment i (16 rows) of plane pl from the stage at `cur` (byte address); `co` = chunk_off of the k-step
     auto w_frag = [&](const unsigned char* cur, int i, int pl, int co) -> half8 {
         if (WIL) return *(const half8*)(cur + NPA * A_PLANE + (wn * 64 + fr + i * 16) * 128 + (((4 * pl + fq) ^ ((fr >> 1) & 7)) * 16));
@@ -247,8 +263,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             return;
         }
         const unsigned char* cur = smem + slot * STAGE;
-        const unsigned char* pAhi = cur;
-        const unsigned char* pAlo = cur + A_PLANE;
         const bool dma = tn >= 0 && !(DBG == 1 && tn > 1);
         unsigned char* nxt = smem + sn * STAGE;
 #pragma unroll
@@ -265,8 +279,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 half8 ah[MG], al[MG];
 #pragma unroll
                 for (int i = 0; i < MG; ++i) {
-                    ah[i] = *(const half8*)(pAhi + a_row + (mh * MG + i) * 16 * ROWB + co);
-                    if (SPLIT == 3) al[i] = *(const half8*)(pAlo + a_row + (mh * MG + i) * 16 * ROWB + co);
+                    ah[i] = a_frag(cur, mh * MG + i, 0, co);
+                    if (SPLIT == 3) al[i] = a_frag(cur, mh * MG + i, 1, co);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MG; ++mt) {
@@ -464,8 +478,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         auto read_a = [&](const unsigned char* cur, int mh) {
 #pragma unroll
             for (int i = 0; i < MH; ++i) {
-                ah[i] = *(const half8*)(cur + a_row + (mh * MH + i) * 16 * ROWB + co);
-                if (SPLIT == 3) al[i] = *(const half8*)(cur + A_PLANE + a_row + (mh * MH + i) * 16 * ROWB + co);
+                ah[i] = a_frag(cur, mh * MH + i, 0, co);
+                if (SPLIT == 3) al[i] = a_frag(cur, mh * MH + i, 1, co);
             }
         };
         auto read_w = [&](const unsigned char* cur) {
@@ -784,9 +798,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 for (int i = 0; i < 2; ++i) {
                     int m = mw + mt_ * 16 + rowh + 8 * i;
                     m = m < g.M ? m : g.M - 1;                        // clamped, always a valid address: masked at the use
-                    const int64_t ro = (int64_t)m * g.ldrh + (nh < g.N ? nh : 0);
+                    const int nc = nh < g.N ? nh : 0;
+                    const int64_t ro = (int64_t)m * g.ldrh + (g.res_il ? ((nc >> 5) << 6) + (nc & 31) : nc);
                     res_h[buf][i] = *(const half8*)((const half_t*)g.res_hi + ro);
-                    res_l[buf][i] = *(const half8*)((const half_t*)g.res_lo + ro);
+                    res_l[buf][i] = g.res_il ? *(const half8*)((const half_t*)g.res_hi + ro + 32) : *(const half8*)((const half_t*)g.res_lo + ro);
                 }
             };
             const bool have_res = MODE == 2 && g.res_hi != nullptr;
@@ -895,7 +910,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                                 split_h2(u, a, b2);
                                 hi[j] = a; lo[j] = b2;
                             }
-                            int64_t off = (int64_t)m * g.ldoh + nh;
+                            int64_t off = (int64_t)m * g.ldoh + (g.out_il ? ((nh >> 5) << 6) + (nh & 31) : nh);   // out_il: [m][n / 32][plane][32]
                             if (g.hm_S > 0) {                              // row part: rows advance by mt * 16 + 8 * i < hm_S
                                 int tk = hm_t + mt * 16 + 8 * i, bi = hm_b;
                                 while (tk >= g.hm_S) { tk -= g.hm_S; ++bi; }
@@ -905,7 +920,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                                 asm volatile("" ::"v"(hi), "v"(lo), "v"(off));
                             } else {
                                 *(half8*)((half_t*)g.out_hi + zh + off) = hi;
-                                if (g.out_lo) *(half8*)((half_t*)g.out_lo + zh + off) = lo;
+                                if (g.out_il) *(half8*)((half_t*)g.out_hi + zh + off + 32) = lo;
+                                else if (g.out_lo) *(half8*)((half_t*)g.out_lo + zh + off) = lo;
                             }
                         }
                     }
@@ -1079,7 +1095,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK_MIN) != 0) return CVLM_E_BADARG;
     if ((g.lda & 7) || (g.ldw & 7) || (g.stride_a & 7) || (g.stride_w & 7)) return CVLM_E_BADARG;
     if (g.split != 1 && g.split != 3) return CVLM_E_BADARG;
-    if (g.split == 3 && (!g.a_lo || !g.w_lo)) return CVLM_E_BADARG;
+    if (g.split == 3 && ((!g.a_lo && !g.a_il) || !g.w_lo)) return CVLM_E_BADARG;
     if (!g.out_f32 && !g.out_hi) return CVLM_E_BADARG;
     if (g.ps_c2 > 0 && ((g.ps_c2 & 3) || g.ps_h <= 0 || g.ps_w <= 0)) return CVLM_E_BADARG;
     if (g.hm_S > 0 && ((g.hm_hd & 3) || g.hm_H <= 0 || (g.M % g.hm_S) || g.N != 3 * g.hm_H * g.hm_hd || !g.out_hi)) return CVLM_E_BADARG;
@@ -1097,7 +1113,17 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         if (!g.out_hi || g.out_f32 || g.residual || g.ps_c2 > 0 || g.batch > 1) return CVLM_E_BADARG;
         if ((g.N & 7) || (g.ldoh & 7) || (g.hm_S > 0 && ((g.hm_hd & 7) || g.hm_S < 128))) return CVLM_E_UNSUPPORTED;
         if (fold && (!g.ln_colsum || (g.act != ACT_NONE && g.act != ACT_GELU && g.act != ACT_QUICKGELU))) return CVLM_E_BADARG;
-        if (h2res && (g.act != ACT_NONE || (g.res_hi && (!g.res_lo || (g.ldrh & 7))))) return CVLM_E_BADARG;
+        if (h2res && (g.act != ACT_NONE || (g.res_hi && ((!g.res_lo && !g.res_il) || (g.ldrh & 7))))) return CVLM_E_BADARG;
+    }
+    const bool il_any = g.a_il || g.out_il || g.res_il;
+    if (il_any) {
+        // 128-byte-row images of activations (ABI 6): split-3, one problem, the LDS-staged epilogues, no head-major / pixel-shuffle store
+        if (g.split != 3 || conv || g.batch > 1 || (g.out_il && g.hm_S > 0) || (g.hm_S > 0 && ((g.hm_hd & 7) || g.hm_S < 256)) || g.ps_c2 > 0 ||
+            (g.N & 7) || (g.ldoh & 7) || (g.stride_oh & 7) ||
+            (g.out_f32 && ((g.ldo & 3) || (g.stride_o & 3))) || (g.residual && ((g.ldr & 3) || (g.stride_r & 3))))
+            return CVLM_E_UNSUPPORTED;
+        if (g.a_il && (!g.w_il || g.M <= 4096 || (g.lda & 7) || g.lda < 2 * (int64_t)g.K)) return CVLM_E_UNSUPPORTED;
+        if (g.res_il && !g.res_hi) return CVLM_E_BADARG;
     }
     GemmParams p;
     p.a = g;
@@ -1131,7 +1157,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     // 128 x 5 = 640 tiles = 2.5 rounds): the columns whose tiles are whole rounds first, the rest (under one round) as the model
     // picks; the h2-residual form included (residual planes and statistics pieces move with the column offset).
     const bool cs_small = g.M <= 4096;
-    if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
+    if (!in_colsplit && colsplit_env && !il_any && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
         (cs_small ? !h2res : colsplit_env >= 2)) {
         const int nby = (g.M + 255) / 256, nbx = (g.N + 255) / 256;
         int c0 = 0;                                                      // column tiles of the first launch: whole rounds of tiles
@@ -1182,6 +1208,8 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     static int wil_env = env_int("CVLM_GEMM_WIL", 1);
     if (live_env) wil_env = env_int("CVLM_GEMM_WIL", 1);
     const bool wil = wil_env && g.w_il && g.split == 3 && !conv && p.a.batch == 1 && g.ldw_il >= 2 * (int64_t)g.K && (g.ldw_il & 7) == 0;
+    const bool ail = g.a_il != 0;
+    if (ail && (!wil || (variant_env != 0 && variant_env != 2 && variant_env != 7))) return CVLM_E_UNSUPPORTED;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
     int variant = variant_env;
     if (variant == 0) {
@@ -1213,6 +1241,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             // a near tie goes to the 256^2 tile: it moves a third fewer L2->LDS bytes per flop, and at the power cap the
             // joules count (proj 32768 x 1280 x 1280 is modelled 305 vs 300 us; with 256^2 tiles the cascade gains 0.85 %)
             variant = (m7 <= 1.04 * m1 && m7 <= 1.04 * m2) ? 5 : (m2 <= m1 ? 2 : 1);
+            if (g.a_il) variant = m7 <= 1.04 * m2 ? 5 : 2;                    // kernels that stage the activation image: 256^2 family, 256 x 128
         } else if (t5 >= 200 && t5 <= 256) variant = 5;                          // one full wave of 256^2 tiles
         else if (t5 >= 1536) {
             const double c2 = (double)(((t2 + 255) / 256) * 256) * 2.0 / 1.08;
@@ -1347,12 +1376,14 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         p.nbx = (g.N + 255) / 256; p.nby = (g.M + 255) / 256;                                                      \
         auto kern_ = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, false, EPI_>;                                            \
         auto kernw_ = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, false, EPI_, false, false, true>;                       \
+        auto kernwa_ = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, false, EPI_, false, false, true, true>;                \
         static bool attr_[16] = {};                                                                                \
         if (cvlm_first_on_device(attr_)) {                                                                         \
             (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);     \
             (void)hipFuncSetAttribute((const void*)kernw_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);    \
+            (void)hipFuncSetAttribute((const void*)kernwa_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);   \
         }                                                                                                          \
-        hipLaunchKernelGGL(wil ? kernw_ : kern_, dim3(p.nbx* p.nby + extra_blocks, 1), dim3(512), smem_, s, p);    \
+        hipLaunchKernelGGL(ail ? kernwa_ : wil ? kernw_ : kern_, dim3(p.nbx* p.nby + extra_blocks, 1), dim3(512), smem_, s, p);    \
     } while (0)
     int extra_blocks = 0;
     if (conv) {
@@ -1405,12 +1436,14 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
                 p.nbx = (g.N + 255) / 256; p.nby = (g.M + 191) / 192;
                 auto k6 = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 6, false, 2>;
                 auto k6w = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 6, false, 2, false, false, true>;
+                auto k6wa = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 6, false, 2, false, false, true, true>;
                 static bool attr6[16] = {};
                 if (cvlm_first_on_device(attr6)) {
                     (void)hipFuncSetAttribute((const void*)k6, hipFuncAttributeMaxDynamicSharedMemorySize, smem6);
                     (void)hipFuncSetAttribute((const void*)k6w, hipFuncAttributeMaxDynamicSharedMemorySize, smem6);
+                    (void)hipFuncSetAttribute((const void*)k6wa, hipFuncAttributeMaxDynamicSharedMemorySize, smem6);
                 }
-                hipLaunchKernelGGL(wil ? k6w : k6, dim3(p.nbx * p.nby, 1), dim3(512), smem6, s, p);
+                hipLaunchKernelGGL(ail ? k6wa : wil ? k6w : k6, dim3(p.nbx * p.nby, 1), dim3(512), smem6, s, p);
                 CVLM_CHECK_LAUNCH();
                 return 0;
             }
@@ -1431,12 +1464,14 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     do {                                                                                                           \
         auto kp = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true, EPI_>;                                                \
         auto kpw = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true, EPI_, false, false, true>;                           \
+        auto kpwa = gemm_nt_kernel<3, 2, 4, 5, 32, 0, 8, true, EPI_, false, false, true, true>;                    \
         static bool attr_p[16] = {};                                                                               \
         if (cvlm_first_on_device(attr_p)) {                                                                        \
             (void)hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);       \
             (void)hipFuncSetAttribute((const void*)kpw, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);      \
+            (void)hipFuncSetAttribute((const void*)kpwa, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);     \
         }                                                                                                          \
-        hipLaunchKernelGGL(wil ? kpw : kp, dim3(cus, 1), dim3(512), smem_p, s, p);                                 \
+        hipLaunchKernelGGL(ail ? kpwa : wil ? kpw : kp, dim3(cus, 1), dim3(512), smem_p, s, p);                    \
     } while (0)
                 if (fold) CVLM_LAUNCH_P(1); else if (h2res) CVLM_LAUNCH_P(2); else CVLM_LAUNCH_P(0);
 #undef CVLM_LAUNCH_P
@@ -1448,15 +1483,19 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             constexpr int smem2 = 3 * 2 * (256 + 128) * 32 * 2;
             p.nbx = (g.N + 127) / 128; p.nby = (g.M + 255) / 256;
             auto k2w = gemm_nt_kernel<3, 4, 2, 3, 32, 0, 4, false, -1, false, false, true>;
+            auto k2wa = gemm_nt_kernel<3, 4, 2, 3, 32, 0, 4, false, -1, false, false, true, true>;
             static bool attr2[16] = {};
-            if (cvlm_first_on_device(attr2))
+            if (cvlm_first_on_device(attr2)) {
                 (void)hipFuncSetAttribute((const void*)k2w, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
-            hipLaunchKernelGGL(k2w, dim3(p.nbx * p.nby, 1), dim3(512), smem2, s, p);
+                (void)hipFuncSetAttribute((const void*)k2wa, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+            }
+            hipLaunchKernelGGL(ail ? k2wa : k2w, dim3(p.nbx * p.nby, 1), dim3(512), smem2, s, p);
         }
         else if (variant == 2) CVLM_LAUNCH(3, 4, 2, 3);
         else if (variant == 7 && lds_staged && p.a.batch == 1) {             /* 256x256, 8 waves, wave groups staggered; one epilogue form */
             if (fold) CVLM_LAUNCH_E(1); else if (h2res) CVLM_LAUNCH_E(2); else CVLM_LAUNCH_E(0);
         }
+        else if (ail) return CVLM_E_UNSUPPORTED;                             /* no other kernel stages the activation image */
         else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* same, every epilogue form (pixel shuffle, odd N, batched) */
 #ifdef CVLM_PROBES
         else if (variant == 77) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 7, 8);        /* probe: s_setprio around MFMA groups */

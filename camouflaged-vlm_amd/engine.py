@@ -79,6 +79,11 @@ class Workspace:
         flat = self._get("h2", name, 2 * n, torch.float16, zero)
         return H2(flat.view((2,) + tuple(shape)))
 
+    def h2il(self, name: str, M: int, C: int) -> hip.H2IL:
+        """Activation in the 128-byte-row image (include/cvlm.h ABI 6): fp16 [M][2 * C], C % 32 == 0."""
+        flat = self._get("h2", name, 2 * M * C, torch.float16, False)
+        return hip.H2IL(flat.view(M, 2 * C))
+
     def scratch(self, name: str, nbytes: int) -> Optional[torch.Tensor]:
         return self._get("u8", name, nbytes, torch.uint8, False) if nbytes > 0 else None
 
@@ -180,6 +185,7 @@ class SamEncoder(_Base):
                  prefix: str = "image_encoder."):
         super().__init__(device, precision)
         self.g = g
+        self.act_il = os.environ.get("CVLM_GEMM_AIL", "1") == "1"   # residual stream / hidden rows as 128-byte-row images (batches)
         P = prefix
         D, Pd = g.embed_dim, g.prompt_dim
         L = lambda name, **kw: Linear(sd[P + name + ".weight"], sd.get(P + name + ".bias"), device, **kw)
@@ -351,6 +357,18 @@ class SamEncoder(_Base):
         self.gemm(prm, self.shared, M, residual=x, out_f32=x)
         hip.row_stats_split(x, X_SCALE, xh, pcs, M, D)
         inv = 1.0 / X_SCALE
+        # Batches (M > 4096): the two activations that only GEMMs touch -- the residual stream and the MLP hidden rows -- live in the
+        # 128-byte-row image (cvlm_gemm a_il / out_il / res_il): the GEMMs that read them as their operand fetch whole L2 lines, as they
+        # do for the weights.  Block 0 reads the planar seed that cvlm_row_stats_split wrote and its proj writes the image; the
+        # attention output stays in planes (the attention kernels write it).  One image: the small-grid kernels read planes only.
+        use_il = (M > 4096 and self.act_il and D % 32 == 0 and HK % 32 == 0 and self.neck0.w_il is not None and
+                  all(b["qkv_f"].w_il is not None and b["lin1_f"].w_il is not None and b["lin2"].w_il is not None for b in self.blocks))
+        xo = xh                                                      # where proj / lin2 write the stream
+        if use_il:
+            xo = ws.h2il("xh_il", M, D)
+            hid = ws.h2il("hid_il", M, HK)
+            hid_prm = hid.cols(g.mlp_dim)
+        hk = {} if use_il else {"ldoh": HK}                          # the image carries its own row stride
         for i, blk in enumerate(self.blocks):
             hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)
             self.gemm(xh, blk["qkv_f"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim), alpha=inv,
@@ -362,12 +380,13 @@ class SamEncoder(_Base):
             else:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
                                rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
-            self.gemm(att, blk["proj"], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=pcs)
+            self.gemm(att, blk["proj"], M, out_h2=xo, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=pcs)
+            xh = xo                                                  # from here on the stream is read where it was written
             hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)
-            self.gemm(xh, blk["lin1_f"], M, out_h2=hid, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE, alpha=inv,
-                      ln_fold=(mrg, blk["lin1_f"].colsum))
+            self.gemm(xh, blk["lin1_f"], M, out_h2=hid, act=ACT_GELU, out_scale=HID_SCALE, alpha=inv,
+                      ln_fold=(mrg, blk["lin1_f"].colsum), **hk)
             if i + 1 < g.depth:
-                self.gemm(feat, self.light[i + 1], M, out_h2=hid_prm, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE)
+                self.gemm(feat, self.light[i + 1], M, out_h2=hid_prm, act=ACT_GELU, out_scale=HID_SCALE, **hk)
                 self.gemm(hid, self.lin2cat[i], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
                           alpha=1.0 / HID_SCALE, row_stats=pcs)
             else:

@@ -47,6 +47,7 @@ class GemmArgs(C.Structure):
         ("row_stats", C.c_void_p),
         ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_c", C.c_int32),
         ("w_il", C.c_void_p), ("ldw_il", C.c_int64),
+        ("a_il", C.c_int32), ("out_il", C.c_int32), ("res_il", C.c_int32),
     ]
 
 
@@ -123,6 +124,39 @@ def gemm_workspace_errors(ws: torch.Tensor) -> int:
     return int(words[0]) + int(words[1])
 
 
+class H2IL:
+    """Split-half activation in the 128-byte-row image of include/cvlm.h (ABI 6): one fp16 tensor [M][2 * C], row m =
+    (hi c0..31 | lo c0..31 | hi c32..63 | lo c32..63 | ...).  Only cvlm_gemm (a_il / out_il / res_il) and cvlm_row_stats_split read or
+    write it; `cols(c0)` is the view that starts at column c0 (c0 % 32 == 0) with the same row stride."""
+
+    __slots__ = ("t",)
+    il = True
+
+    def __init__(self, t: torch.Tensor):
+        assert t.dtype == torch.float16 and t.dim() == 2 and t.stride(1) == 1
+        self.t = t
+
+    @staticmethod
+    def empty(M: int, C_: int, device="cuda") -> "H2IL":
+        assert C_ % 32 == 0
+        return H2IL(torch.empty(M, 2 * C_, dtype=torch.float16, device=device))
+
+    @staticmethod
+    def from_planes(x: "H2") -> "H2IL":
+        return H2IL(interleave_planes(x))
+
+    def cols(self, c0: int) -> "H2IL":
+        assert c0 % 32 == 0
+        return H2IL(self.t[:, 2 * c0:])
+
+    def planes(self) -> "H2":
+        M, C2 = self.t.shape
+        return H2(self.t.reshape(M, C2 // 64, 2, 32).permute(2, 0, 1, 3).reshape(2, M, C2 // 2).contiguous())
+
+    def float(self) -> torch.Tensor:
+        return self.planes().float()
+
+
 def interleave_planes(w: "H2") -> torch.Tensor:
     """[2][N][K] planes -> fp16 [N][2K] with row n = (hi k0..31 | lo k0..31 | hi k32..63 | lo k32..63 | ...): the `w_il` image of
     cvlm_gemm (include/cvlm.h, ABI 6).  K % 32 == 0."""
@@ -197,7 +231,10 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     (plain stores, bit-reproducible: nothing to zero)."""
     _on_current_device(a.t)
     g = GemmArgs()
-    g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
+    if getattr(a, "il", False):
+        g.a_hi, g.a_lo, g.lda, g.stride_a, g.a_il = a.t.data_ptr(), 0, a.t.stride(0), 0, 1
+    else:
+        g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
     g.w_hi, g.w_lo, g.ldw, g.stride_w = w.hi.data_ptr(), w.lo.data_ptr(), ldw if ldw is not None else K, stride_w
     if w_il is not None:
         assert w_il.dtype == torch.float16 and w_il.dim() == 2 and w_il.shape[1] >= 2 * K and w_il.is_contiguous() and batch == 1
@@ -205,9 +242,11 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     g.bias = _p(bias)
     g.residual, g.ldr, g.stride_r = _p(residual), (ldr if ldr is not None else N), stride_r
     g.out_f32, g.ldo, g.stride_o = _p(out_f32), (ldo if ldo is not None else N), stride_o
-    if out_h2 is not None:
-        g.out_hi, g.out_lo = out_h2.hi.data_ptr(), out_h2.lo.data_ptr()
     g.ldoh, g.stride_oh = (ldoh if ldoh is not None else N), stride_oh
+    if out_h2 is not None and getattr(out_h2, "il", False):
+        g.out_hi, g.out_lo, g.ldoh, g.out_il = out_h2.t.data_ptr(), 0, out_h2.t.stride(0), 1
+    elif out_h2 is not None:
+        g.out_hi, g.out_lo = out_h2.hi.data_ptr(), out_h2.lo.data_ptr()
     g.M, g.N, g.K, g.batch = M, N, K, batch
     g.alpha, g.act, g.split = alpha, act, split
     if pixel_shuffle is not None:
@@ -220,7 +259,10 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
         g.ln_stats, g.ln_colsum = ln_fold[0].data_ptr(), ln_fold[1].data_ptr()
     if residual_h2 is not None:
         r, rs = residual_h2
-        g.res_hi, g.res_lo, g.ldrh, g.res_scale = r.hi.data_ptr(), r.lo.data_ptr(), (ldrh if ldrh is not None else N), rs
+        if getattr(r, "il", False):
+            g.res_hi, g.res_lo, g.ldrh, g.res_scale, g.res_il = r.t.data_ptr(), 0, r.t.stride(0), rs, 1
+        else:
+            g.res_hi, g.res_lo, g.ldrh, g.res_scale = r.hi.data_ptr(), r.lo.data_ptr(), (ldrh if ldrh is not None else N), rs
     if row_stats is not None:
         assert tuple(row_stats.shape) == (stats_pieces(N), M, 2) and row_stats.is_contiguous(), "row_stats: [pieces][M][2]"
         g.row_stats = row_stats.data_ptr()

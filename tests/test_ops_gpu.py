@@ -209,6 +209,59 @@ def test_gemm_interleaved_weights_same_bits(hip, monkeypatch, M, N, K, variant, 
         assert hip.gemm_workspace_errors(ws) == 0
 
 
+@pytest.mark.parametrize("M,N,K,variant,use_ws", [(16640, 1280, 256, "7", False),      # persistent 256^2 kernel
+                                                   (8192, 1280, 320, "7", True),        # one-pass 256^2 kernel
+                                                   (33000, 1280, 128, "0", True),       # 2.5+ rounds: tail parts behind the whole tiles
+                                                   (8200, 1160, 256, "2", True)])       # 256 x 128 tiles, ragged M / N
+def test_gemm_interleaved_activations_same_bits(hip, monkeypatch, M, N, K, variant, use_ws):
+    """ABI 6: activations that only GEMMs touch travel as 128-byte-row images (a_il / out_il / res_il).  Operand image in, output image
+    out, residual image in place: the bits of the planar launches, for the plain, LayerNorm-folded and h2-residual epilogues."""
+    from camouflaged_vlm_amd.engine import LnLinear
+    monkeypatch.setenv("CVLM_GEMM_VARIANT", variant)
+    a, w, bias, res = rnd(M, K, seed=81), rnd(N, K, seed=82, scale=K ** -0.5), rnd(N, seed=83), rnd(M, N, seed=84)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    Wil, Ail = hip.interleave_planes(W), hip.H2IL.from_planes(A)
+    assert torch.equal(Ail.planes().t, A.t)
+    ws = hip.new_gemm_workspace("cuda") if use_ws else None
+    XS = 0.25
+    x = rnd(M, K, seed=85) * 2.0
+    gamma, beta = 1.0 + 0.1 * rnd(K, seed=86), 0.05 * rnd(K, seed=87)
+    xh, st, mrg = hip.H2.empty(M, K), torch.empty(hip.stats_pieces(K), M, 2, device="cuda"), torch.empty(M, 2, device="cuda")
+    hip.row_stats_split(x.cuda(), XS, xh, st, M, K)
+    hip.ln_stats_merge(st, M, K, 1e-6, mrg, hip.new_gemm_workspace("cuda"))
+    xil = hip.H2IL.from_planes(xh)
+    lin = LnLinear(w, bias, gamma, beta, "cuda")
+    lin_il = hip.interleave_planes(lin.w)
+    NP = N + 64 - N % 32 if N % 32 else N + 64                                  # image width: a multiple of 32, wider than N
+    # planar reference launches
+    o = hip.H2.empty(M, N); oh = hip.H2.empty(M, N)
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o, workspace=ws, w_il=Wil)
+    hip.gemm(xh, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=1, out_h2=oh, ln_fold=(mrg, lin.colsum), workspace=ws, w_il=lin_il)
+    o2 = hip.H2(hip.H2.pack(res * XS).t.cuda())
+    st_ref = torch.full((hip.stats_pieces(N), M, 2), float("nan"), device="cuda")
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=o2, residual_h2=(o2, 1.0 / XS), out_scale=XS, row_stats=st_ref, workspace=ws, w_il=Wil)
+    # the same through images
+    oi = hip.H2IL(torch.full((M, 2 * NP), float("nan"), dtype=torch.float16, device="cuda"))
+    hip.gemm(Ail, W, M, N, K, bias=bias.cuda(), out_h2=oi, workspace=ws, w_il=Wil)
+    ohi = hip.H2IL(torch.full((M, 2 * NP), float("nan"), dtype=torch.float16, device="cuda"))
+    hip.gemm(xil, lin.w, M, N, lin.K, bias=lin.bias, alpha=lin.alpha / XS, act=1, out_h2=ohi, ln_fold=(mrg, lin.colsum), workspace=ws, w_il=lin_il)
+    r_pl = hip.H2.zeros(M, NP)
+    r_pl.t[:, :, :N] = hip.H2.pack(res * XS).t.cuda()
+    o2i = hip.H2IL.from_planes(r_pl)
+    st_il = torch.full((hip.stats_pieces(N), M, 2), float("nan"), device="cuda")
+    hip.gemm(Ail, W, M, N, K, bias=bias.cuda(), out_h2=o2i, residual_h2=(o2i, 1.0 / XS), out_scale=XS, row_stats=st_il, workspace=ws, w_il=Wil)
+    torch.cuda.synchronize()
+    N8 = N
+    assert torch.equal(oi.planes().t[:, :, :N8], o.t)
+    assert torch.equal(ohi.planes().t[:, :, :N8], oh.t)
+    assert torch.equal(o2i.planes().t[:, :, :N8], o2.t) and torch.equal(st_il, st_ref)
+    assert bool(torch.isnan(oi.planes().t[:, :, N8 + (-N8) % 32:]).all())            # nothing written past the last chunk of N
+    ref = A.float().cpu().double() @ W.float().cpu().double().t() + bias.double()
+    assert relerr(oi.float()[:, :N].cpu().double(), ref) < 3e-6
+    if ws is not None:
+        assert hip.gemm_workspace_errors(ws) == 0
+
+
 def test_gemm_column_split_partial_round_h2res(hip, monkeypatch):
     """CVLM_GEMM_COLSPLIT=2: a grid of several rounds with a partial last one (32 x 10 tiles of 256^2 = 1.25 rounds) as whole rounds
     + the remaining columns, h2-residual form: outputs, in-place residual and the statistics pieces carry the bits of the
