@@ -1348,7 +1348,15 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             (void)hipFuncSetAttribute((const void*)ksk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);      \
         hipLaunchKernelGGL(ksk, dim3(p.nbx* p.nby * p.sk_parts, 1), dim3(WM_ * 2 * 64), smem_sk, s, p);             \
     } while (0)
-            if (small_ring == 4 && w8_env) CVLM_LAUNCH_SK(4, 2, 14, 4);
+            if (small_ring == 4 && w8_env && wil) {                       /* the same, weight from the interleaved image */
+                constexpr int smem_sk = 4 * 2 * (128 + 128) * 32 * 2;
+                auto ksk = gemm_nt_kernel<3, 4, 2, 14, 32, 0, 2, false, -1, false, true, true>;
+                static bool attr_skw[16] = {};
+                if (cvlm_first_on_device(attr_skw))
+                    (void)hipFuncSetAttribute((const void*)ksk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);
+                hipLaunchKernelGGL(ksk, dim3(p.nbx * p.nby * p.sk_parts, 1), dim3(512), smem_sk, s, p);
+            }
+            else if (small_ring == 4 && w8_env) CVLM_LAUNCH_SK(4, 2, 14, 4);
             else if (small_ring == 3) CVLM_LAUNCH_SK(2, 4, 13, 3);
             else if (small_ring == 4) CVLM_LAUNCH_SK(2, 4, 14, 4);
             else CVLM_LAUNCH_SK(2, 4, 2, 2);
@@ -1369,6 +1377,20 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         if (smem_ > 48 * 1024 && cvlm_first_on_device(attr_))                                                             \
             (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_); \
         hipLaunchKernelGGL(kern_, dim3(p.nbx* p.nby + extra_blocks, p.a.batch), dim3(WM* WN * 64), smem_, s, p); \
+    } while (0)
+#define CVLM_LAUNCH_W(WM, WN, NS, MT)    /* split-3 ring kernels: weight from the interleaved image when there is one */       \
+    do {                                                                                                           \
+        constexpr int smem_ = (NS - 10) * 2 * (WM * MT * 16 + WN * 64) * 32 * 2;                                   \
+        p.nbx = (g.N + WN * 64 - 1) / (WN * 64);                                                                   \
+        p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                         \
+        auto kern_ = gemm_nt_kernel<3, WM, WN, NS, 32, 0, MT>;                                                     \
+        auto kernw_ = gemm_nt_kernel<3, WM, WN, NS, 32, 0, MT, false, -1, false, false, true>;                     \
+        static bool attr_[16] = {};                                                                                \
+        if (cvlm_first_on_device(attr_)) {                                                                         \
+            (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);     \
+            (void)hipFuncSetAttribute((const void*)kernw_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);    \
+        }                                                                                                          \
+        hipLaunchKernelGGL(wil ? kernw_ : kern_, dim3(p.nbx* p.nby + extra_blocks, p.a.batch), dim3(WM* WN * 64), smem_, s, p); \
     } while (0)
 #define CVLM_LAUNCH_E(EPI_)                                                                                        \
     do {                                                                                                           \
@@ -1524,8 +1546,8 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #endif
         else if (variant == 1 && !conv && p.a.batch == 1 && g.M <= 4096 && (small_ring = pick_ring((long)((g.M + 127) / 128) * ((g.N + 127) / 128))) == 3) CVLM_LAUNCH(3, 2, 2, 13);
         else if (small_ring == 4 && (w8_env == 2 || (w8_env == 1 && (long)((g.M + 63) / 64) * ((g.N + 127) / 128) <= 256)))
-            CVLM_LAUNCH_D(3, 4, 2, 14, 32, 0, 1);                            /* 64 x 128 tiles, eight waves of 16 x 64 */
-        else if (small_ring == 4 && w8_env) CVLM_LAUNCH_D(3, 4, 2, 14, 32, 0, 2);   /* 128^2 tiles, eight waves of 32 x 64 */
+            CVLM_LAUNCH_W(4, 2, 14, 1);                                      /* 64 x 128 tiles, eight waves of 16 x 64 */
+        else if (small_ring == 4 && w8_env) CVLM_LAUNCH_W(4, 2, 14, 2);     /* 128^2 tiles, eight waves of 32 x 64 */
         else if (small_ring == 4) CVLM_LAUNCH(3, 2, 2, 14);
         else if (small_ring == 5) CVLM_LAUNCH(3, 2, 2, 15);
         else CVLM_LAUNCH(3, 2, 2, 2);
@@ -1542,6 +1564,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #undef CVLM_LAUNCH
 #undef CVLM_LAUNCH_D
 #undef CVLM_LAUNCH_E
+#undef CVLM_LAUNCH_W
     CVLM_CHECK_LAUNCH();
     return 0;
 }

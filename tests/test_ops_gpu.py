@@ -168,7 +168,10 @@ def test_gemm_column_split_one_image(hip, monkeypatch, M, N, K):
                                                    (8192, 1280, 320, "7", True),        # 160 tiles: one-pass 256^2 kernel
                                                    (9296, 1024, 512, "0", True),        # 192-row tiles (h2-residual form), 256^2 otherwise
                                                    (8200, 1160, 256, "2", True),        # 256 x 128 tiles, ragged M / N
-                                                   (4096, 5120, 256, "0", True)])       # one image's lin1: column split + interleaved
+                                                   (4096, 5120, 256, "0", True),        # one image's lin1: column split + interleaved
+                                                   (581, 1024, 1024, "0", True),        # small grid: 64 x 128 tiles on the deep ring
+                                                   (581, 4096, 1024, "0", True),        # small grid: 128^2 tiles, eight waves
+                                                   (581, 1024, 4096, "0", True)])       # small grid: split-K parts
 def test_gemm_interleaved_weights_same_bits(hip, monkeypatch, M, N, K, variant, use_ws):
     """ABI 6: the big-tile kernels stage the weight from the image whose planes are interleaved per 32 k-elements (whole 128-byte
     lines).  Same fragments, same MFMA order: plain, LayerNorm-folded and h2-residual launches give the bits of the planar launch."""
