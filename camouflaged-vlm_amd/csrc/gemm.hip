@@ -90,7 +90,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             (g.N & 7) || (g.ldoh & 7) || (g.stride_oh & 7) ||
             (g.out_f32 && ((g.ldo & 3) || (g.stride_o & 3))) || (g.residual && ((g.ldr & 3) || (g.stride_r & 3))))
             return CVLM_E_UNSUPPORTED;
-        if (g.a_il && (!g.w_il || g.M <= 4096 || (g.lda & 7) || g.lda < 2 * (int64_t)g.K)) return CVLM_E_UNSUPPORTED;
+        if (g.a_il && (!g.w_il || (g.lda & 7) || g.lda < 2 * (int64_t)g.K)) return CVLM_E_UNSUPPORTED;
         if (g.res_il && !g.res_hi) return CVLM_E_BADARG;
     }
     GemmParams p;
@@ -125,8 +125,8 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     // 128 x 5 = 640 tiles = 2.5 rounds): the columns whose tiles are whole rounds first, the rest (under one round) as the model
     // picks; the h2-residual form included (residual planes and statistics pieces move with the column offset).
     const bool cs_small = g.M <= 4096;
-    if (!in_colsplit && colsplit_env && !il_any && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
-        (cs_small ? !h2res : colsplit_env >= 2)) {
+    if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
+        (cs_small ? !h2res : (colsplit_env >= 2 && !il_any))) {
         const int nby = (g.M + 255) / 256, nbx = (g.N + 255) / 256;
         int c0 = 0;                                                      // column tiles of the first launch: whole rounds of tiles
         bool ok = false;
@@ -154,7 +154,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             if (g.ln_colsum) a2.ln_colsum = g.ln_colsum + n0;
             if (g.residual) a2.residual = g.residual + n0;
             if (g.out_f32) a2.out_f32 = g.out_f32 + n0;
-            if (g.out_hi) a2.out_hi = (char*)g.out_hi + (int64_t)n0 * 2;
+            if (g.out_hi) a2.out_hi = (char*)g.out_hi + (int64_t)n0 * 2 * (g.out_il ? 2 : 1);   // image: column c0 starts 2 * c0 halves into a row
             if (g.out_lo) a2.out_lo = (char*)g.out_lo + (int64_t)n0 * 2;
             in_colsplit = 1;
             int rc = cvlm_gemm(&a1, stream);
@@ -292,8 +292,11 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         }
         const bool fast_ok = true;
         (void)fast_ok;
+        // activation image: of the 128^2 family only the eight-wave ring kernels stage it (one round of workgroups)
+        const bool ail1_ok = !ail || (ring_on && w8_env != 0 && t1 <= 256);
+        if (ail && skS > 1 && !(ring_on && (long)t1 * skS <= 256)) { skS = 1; msk = 1e30; }
         if (variant_env == 0) {
-            double best = m1;
+            double best = ail1_ok ? m1 : 1e30;
             variant = 1;
             if (m2 < best) { best = m2; variant = 2; }
             if (m7 < best) { best = m7; variant = 5; small_tail_S = tailS > 0 ? tailS : -1; }
@@ -316,13 +319,17 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             (void)hipFuncSetAttribute((const void*)ksk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);      \
         hipLaunchKernelGGL(ksk, dim3(p.nbx* p.nby * p.sk_parts, 1), dim3(WM_ * 2 * 64), smem_sk, s, p);             \
     } while (0)
-            if (small_ring == 4 && w8_env && wil) {                       /* the same, weight from the interleaved image */
+            if (ail && !(small_ring == 4 && w8_env && wil)) return CVLM_E_UNSUPPORTED;
+            if (small_ring == 4 && w8_env && wil) {                       /* the same, operands from the 128-byte-row images */
                 constexpr int smem_sk = 4 * 2 * (128 + 128) * 32 * 2;
                 auto ksk = gemm_nt_kernel<3, 4, 2, 14, 32, 0, 2, false, -1, false, true, true>;
+                auto kska = gemm_nt_kernel<3, 4, 2, 14, 32, 0, 2, false, -1, false, true, true, true>;
                 static bool attr_skw[16] = {};
-                if (cvlm_first_on_device(attr_skw))
+                if (cvlm_first_on_device(attr_skw)) {
                     (void)hipFuncSetAttribute((const void*)ksk, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);
-                hipLaunchKernelGGL(ksk, dim3(p.nbx * p.nby * p.sk_parts, 1), dim3(512), smem_sk, s, p);
+                    (void)hipFuncSetAttribute((const void*)kska, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sk);
+                }
+                hipLaunchKernelGGL(ail ? kska : ksk, dim3(p.nbx * p.nby * p.sk_parts, 1), dim3(512), smem_sk, s, p);
             }
             else if (small_ring == 4 && w8_env) CVLM_LAUNCH_SK(4, 2, 14, 4);
             else if (small_ring == 3) CVLM_LAUNCH_SK(2, 4, 13, 3);
@@ -353,12 +360,14 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         p.nby = (g.M + WM * MT * 16 - 1) / (WM * MT * 16);                                                         \
         auto kern_ = gemm_nt_kernel<3, WM, WN, NS, 32, 0, MT>;                                                     \
         auto kernw_ = gemm_nt_kernel<3, WM, WN, NS, 32, 0, MT, false, -1, false, false, true>;                     \
+        auto kernwa_ = gemm_nt_kernel<3, WM, WN, NS, 32, 0, MT, false, -1, false, false, true, true>;              \
         static bool attr_[16] = {};                                                                                \
         if (cvlm_first_on_device(attr_)) {                                                                         \
             (void)hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);     \
             (void)hipFuncSetAttribute((const void*)kernw_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);    \
+            (void)hipFuncSetAttribute((const void*)kernwa_, hipFuncAttributeMaxDynamicSharedMemorySize, smem_);   \
         }                                                                                                          \
-        hipLaunchKernelGGL(wil ? kernw_ : kern_, dim3(p.nbx* p.nby + extra_blocks, p.a.batch), dim3(WM* WN * 64), smem_, s, p); \
+        hipLaunchKernelGGL(ail ? kernwa_ : wil ? kernw_ : kern_, dim3(p.nbx* p.nby + extra_blocks, p.a.batch), dim3(WM* WN * 64), smem_, s, p); \
     } while (0)
 #define CVLM_LAUNCH_E(EPI_)                                                                                        \
     do {                                                                                                           \
@@ -376,6 +385,8 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         hipLaunchKernelGGL(ail ? kernwa_ : wil ? kernw_ : kern_, dim3(p.nbx* p.nby + extra_blocks, 1), dim3(512), smem_, s, p);    \
     } while (0)
     int extra_blocks = 0;
+    // slots of the deep ring for a plain (whole-tile) 128^2-family launch of a small grid, 0: the two-slot loop
+    const int small_ring_pick = (g.split == 3 && !conv && p.a.batch == 1 && g.M <= 4096) ? pick_ring((long)((g.M + 127) / 128) * ((g.N + 127) / 128)) : 0;
     if (conv) {
         // 256 x 64 tiles (4 waves, 2 workgroups per CU): the edge head's N is 32 / 64, the neck's 256
         constexpr int smem_c = 2 * 2 * (256 + 64) * 32 * 2;
@@ -485,6 +496,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 7 && lds_staged && p.a.batch == 1) {             /* 256x256, 8 waves, wave groups staggered; one epilogue form */
             if (fold) CVLM_LAUNCH_E(1); else if (h2res) CVLM_LAUNCH_E(2); else CVLM_LAUNCH_E(0);
         }
+        else if (variant == 1 && small_ring_pick == 4 && (w8_env == 2 || (w8_env == 1 && (long)((g.M + 63) / 64) * ((g.N + 127) / 128) <= 256)))
+            CVLM_LAUNCH_W(4, 2, 14, 1);                                      /* 64 x 128 tiles, eight waves of 16 x 64 */
+        else if (variant == 1 && small_ring_pick == 4 && w8_env) CVLM_LAUNCH_W(4, 2, 14, 2);     /* 128^2 tiles, eight waves of 32 x 64 */
         else if (ail) return CVLM_E_UNSUPPORTED;                             /* no other kernel stages the activation image */
         else if (variant == 7) CVLM_LAUNCH_D(3, 2, 4, 5, 32, 0, 8);          /* same, every epilogue form (pixel shuffle, odd N, batched) */
 #ifdef CVLM_PROBES
@@ -512,12 +526,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 25) CVLM_LAUNCH_D(3, 2, 4, 2, 32, 2, 8);
         else if (variant == 3) CVLM_LAUNCH(3, 2, 2, 3);
 #endif
-        else if (variant == 1 && !conv && p.a.batch == 1 && g.M <= 4096 && (small_ring = pick_ring((long)((g.M + 127) / 128) * ((g.N + 127) / 128))) == 3) CVLM_LAUNCH(3, 2, 2, 13);
-        else if (small_ring == 4 && (w8_env == 2 || (w8_env == 1 && (long)((g.M + 63) / 64) * ((g.N + 127) / 128) <= 256)))
-            CVLM_LAUNCH_W(4, 2, 14, 1);                                      /* 64 x 128 tiles, eight waves of 16 x 64 */
-        else if (small_ring == 4 && w8_env) CVLM_LAUNCH_W(4, 2, 14, 2);     /* 128^2 tiles, eight waves of 32 x 64 */
-        else if (small_ring == 4) CVLM_LAUNCH(3, 2, 2, 14);
-        else if (small_ring == 5) CVLM_LAUNCH(3, 2, 2, 15);
+        else if (variant == 1 && small_ring_pick == 3) CVLM_LAUNCH(3, 2, 2, 13);
+        else if (variant == 1 && small_ring_pick == 4) CVLM_LAUNCH(3, 2, 2, 14);
+        else if (variant == 1 && small_ring_pick == 5) CVLM_LAUNCH(3, 2, 2, 15);
         else CVLM_LAUNCH(3, 2, 2, 2);
     } else {
         if (group_env > 0) p.group_m = group_env;

@@ -1059,4 +1059,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 3, 32, 0, 4, false, -1, false, false, true, true)              \
     CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 1, false, -1, false, false, true, false)            \
     CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 2, false, -1, false, false, true, false)            \
-    CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 2, false, -1, false, true, true, false)
+    CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 2, false, -1, false, true, true, false)             \
+    CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 1, false, -1, false, false, true, true)             \
+    CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 2, false, -1, false, false, true, true)             \
+    CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 2, false, -1, false, true, true, true)

@@ -185,7 +185,9 @@ class SamEncoder(_Base):
                  prefix: str = "image_encoder."):
         super().__init__(device, precision)
         self.g = g
-        self.act_il = os.environ.get("CVLM_GEMM_AIL", "1") == "1"   # residual stream / hidden rows as 128-byte-row images (batches)
+        # residual stream / hidden rows as 128-byte-row images: CVLM_GEMM_AIL = 1 (default) always, b batches only (M > 4096), 0 never
+        self.act_il = os.environ.get("CVLM_GEMM_AIL", "1") != "0"
+        self.act_il_small = os.environ.get("CVLM_GEMM_AIL", "1") not in ("0", "b")
         P = prefix
         D, Pd = g.embed_dim, g.prompt_dim
         L = lambda name, **kw: Linear(sd[P + name + ".weight"], sd.get(P + name + ".bias"), device, **kw)
@@ -357,11 +359,11 @@ class SamEncoder(_Base):
         self.gemm(prm, self.shared, M, residual=x, out_f32=x)
         hip.row_stats_split(x, X_SCALE, xh, pcs, M, D)
         inv = 1.0 / X_SCALE
-        # Batches (M > 4096): the two activations that only GEMMs touch -- the residual stream and the MLP hidden rows -- live in the
-        # 128-byte-row image (cvlm_gemm a_il / out_il / res_il): the GEMMs that read them as their operand fetch whole L2 lines, as they
-        # do for the weights.  Block 0 reads the planar seed that cvlm_row_stats_split wrote and its proj writes the image; the
-        # attention output stays in planes (the attention kernels write it).  One image: the small-grid kernels read planes only.
-        use_il = (M > 4096 and self.act_il and D % 32 == 0 and HK % 32 == 0 and self.neck0.w_il is not None and
+        # The two activations that only GEMMs touch -- the residual stream and the MLP hidden rows -- live in the 128-byte-row image
+        # (cvlm_gemm a_il / out_il / res_il): the GEMMs that read them as their operand fetch whole L2 lines, as they do for the
+        # weights.  Block 0 reads the planar seed that cvlm_row_stats_split wrote and its proj writes the image; the attention
+        # output stays in planes (the attention kernels write it).
+        use_il = ((M > 4096 or self.act_il_small) and self.act_il and pr.gemm == 3 and D % 32 == 0 and HK % 32 == 0 and self.neck0.w_il is not None and
                   all(b["qkv_f"].w_il is not None and b["lin1_f"].w_il is not None and b["lin2"].w_il is not None for b in self.blocks))
         xo = xh                                                      # where proj / lin2 write the stream
         if use_il:

@@ -105,7 +105,7 @@ typedef struct cvlm_gemm_args {
     const void* w_il; int64_t ldw_il;
     /* ABI 6 -- the same 128-byte-row image for ACTIVATIONS that only GEMMs touch (the h2 residual stream and the MLP hidden
      * activations of a transformer block): t_il[m][c / 32][plane][c % 32], one pointer, row stride in halves.
-     *   a_il:   a_hi is such an image (a_lo unused), lda its row stride; needs w_il; M > 4096 (the one-image kernels read planes only)
+     *   a_il:   a_hi is such an image (a_lo unused), lda its row stride; needs w_il
      *   out_il: out_hi is such an image (out_lo unused), ldoh its row stride; h2 output of the LDS-staged epilogues, not head-major
      *   res_il: res_hi is such an image (res_lo unused), ldrh its row stride
      * A column offset c0 (c0 % 32 == 0) into an image is the pointer offset 2 * c0 halves. */

@@ -215,7 +215,13 @@ def test_gemm_interleaved_weights_same_bits(hip, monkeypatch, M, N, K, variant, 
 @pytest.mark.parametrize("M,N,K,variant,use_ws", [(16640, 1280, 256, "7", False),      # persistent 256^2 kernel
                                                    (8192, 1280, 320, "7", True),        # one-pass 256^2 kernel
                                                    (33000, 1280, 128, "0", True),       # 2.5+ rounds: tail parts behind the whole tiles
-                                                   (8200, 1160, 256, "2", True)])       # 256 x 128 tiles, ragged M / N
+                                                   (8200, 1160, 256, "2", True),        # 256 x 128 tiles, ragged M / N
+                                                   (4096, 3840, 256, "0", True),        # one image: one round of 256^2 tiles
+                                                   (4096, 5120, 256, "0", True),        # one image's lin1: column split, image output
+                                                   (4096, 1280, 1280, "0", True),       # one image: K-parts / tail chain
+                                                   (581, 1024, 1024, "0", True),        # small grid: 64 x 128 tiles on the deep ring
+                                                   (581, 4096, 1024, "0", True),        # small grid: 128^2 tiles, eight waves
+                                                   (581, 1024, 4096, "0", True)])       # small grid: split-K parts
 def test_gemm_interleaved_activations_same_bits(hip, monkeypatch, M, N, K, variant, use_ws):
     """ABI 6: activations that only GEMMs touch travel as 128-byte-row images (a_il / out_il / res_il).  Operand image in, output image
     out, residual image in place: the bits of the planar launches, for the plain, LayerNorm-folded and h2-residual epilogues."""
