@@ -820,7 +820,10 @@ class ClipModel(_Base):
         ws, pr, c = self.ws, self.prec, self.c
         M, inv = Bn * L, 1.0 / X_SCALE
         xh, qkv, att = ws.h2("vxh", M, Wd), ws.h2("vqkv", M, 3 * Wd), ws.h2("vatt", M, Wd)
-        hid = ws.h2("vhid", M, 4 * Wd)
+        # the MLP hidden rows are written by c_fc and read by c_proj only: they travel as a 128-byte-row image (SamEncoder._blocks_folded)
+        hid_il = (os.environ.get("CVLM_GEMM_AIL", "1") not in ("0", "b") or M > 4096) and os.environ.get("CVLM_GEMM_AIL", "1") != "0" \
+            and pr.gemm == 3 and (4 * Wd) % 32 == 0 and all(b["pj"].w_il is not None and b["fc_f"].w_il is not None for b in self.vblocks)
+        hid = ws.h2il("vhid_il", M, 4 * Wd) if hid_il else ws.h2("vhid", M, 4 * Wd)
         pcs, mrg = ws.f32("vln_pieces", hip.stats_pieces(Wd), M, 2), ws.f32("vln_merged", M, 2)
         gws = self.ws.gemm_ws()
         hip.row_stats_split(x.view(M, Wd), X_SCALE, xh, pcs, M, Wd)
