@@ -9,11 +9,15 @@ Per-pixel numpy restatement of what the reference does after `infer_test` for on
   * `iou_*`           recorder/ovcos_metricer.py:126-180 -- the reference's own IOU class.
   * `Classification`  recorder/new_evaluator.py:47-59,68-71 -- top-1 / top-5.
 
-Pinning: `iou_changeable`, `iou_adaptive` and `Classification` are checked against the reference's code run in this
-container (tests/golden/evaltail.npz, tools/make_evaltail_golden.py).  MAE / F / E / S measures restate the published
-pysodmetrics 1.4.2 algorithm and cv2.resize restates OpenCV 4.8's float32 linear path; neither dependency is
-available here, so for those functions **parity is unpinned**.  The weighted F-measure runs on scipy's exact
-distance transform and convolution, the same routines pysodmetrics calls.
+Pinning (round 4): **every metric is pinned to the reference's own code run in this container**
+(tests/golden/evaltail.npz, tools/make_evaltail_golden.py): the reference carries the pysodmetrics classes in-tree as
+recorder/sod_metric.py:39-581 (the code `utils.calc_cod` runs, utils.py:143-165); the generator registers them under the
+`py_sod_metrics` names recorder/ovcos_metricer.py imports and drives the real `OVCOSMetricer.step / show`, `calc_cod` and
+`Classification`.  Gated per image (Sm, wFm, MAE, adaptive and 256-point F / E / IoU curves, class match and mismatch,
+empty / full ground truth, flat prediction, non-square sizes) and on the aggregated `show()` dict.  Only `cv2.resize`
+(OpenCV 4.8's float32 linear path, restated in `resize_linear_f32`; the package is not installed and nothing of it is in
+/root/reference) stays **parity unpinned**.  The weighted F-measure runs on scipy's exact distance transform and
+convolution, the same routines the reference calls (sod_metric.py:4-5).
 """
 from __future__ import annotations
 
@@ -60,7 +64,7 @@ def mask_to_u8(logits: np.ndarray, h: int, w: int) -> np.ndarray:
     return (resize_linear_f32(sigmoid_f32(logits), h, w) * 255).astype(np.uint8)
 
 
-# ---- pysodmetrics 1.4.2 ----------------------------------------------------------------------------------------------
+# ---- recorder/sod_metric.py:12-581 (= pysodmetrics 1.4.2) ----------------------------------------------------------------------------------------------
 def prepare_data(pred: np.ndarray, gt: np.ndarray):
     gt = gt > 128
     pred = pred / 255
@@ -170,7 +174,7 @@ def sm(pred, gt, alpha=0.5) -> float:
             return float(1 - np.mean(pred))
         if y == 1:
             return float(np.mean(pred))
-        g = gt.astype(np.float64)
+        g = gt                                               # bool, as in sod_metric.py:213-221: float32 maps stay float32
         obj = y * _s_object(pred * g, g) + (1 - y) * _s_object((1 - pred) * (1 - g), 1 - g)
         cx, cy = centroid(gt)
         h, w = gt.shape
@@ -195,8 +199,9 @@ def gauss2d(shape=(7, 7), sigma=5.0) -> np.ndarray:
 
 
 def wfm(pred, gt, beta=1.0) -> float:
-    """pysodmetrics 1.4.2 `WeightedFmeasure.cal_wfm` (Margolin et al.), as called by ovcos_metricer.py:49-66 with
-    beta = 1; needs scipy (the package pysodmetrics itself builds on) for the exact Euclidean distance transform."""
+    """`WeightedFmeasure.cal_wfm` (recorder/sod_metric.py:516-560, Margolin et al.), as called by ovcos_metricer.py:49-66
+    with beta = 1 and by `calc_cod` with the class default 0.3 (sod_metric.py:491); scipy's exact Euclidean distance
+    transform and `convolve`, as there."""
     from scipy.ndimage import convolve, distance_transform_edt as bwdist
     if np.all(~gt):
         return 0.0
@@ -253,6 +258,21 @@ def aggregate(steps: list) -> dict:
         res[f"max{m}"] = float(curve.max())
         res[f"avg{m}"] = float(curve.mean())
     return res
+
+
+def calc_cod(y_pred: np.ndarray, y_true: np.ndarray):
+    """utils.py:143-165 `calc_cod`: (B,1,H,W) float32 probabilities and {0, 1} ground truth -> (sm, em, wfm, mae), each the
+    batch mean of the in-tree sod_metric classes fed `y * 255` as float32 (no uint8 step: Sm / MAE / wFm see the continuous
+    map, only the E curve quantises, sod_metric.py:420); wFm at the class default beta = 0.3; em = mean of the mean curve."""
+    sms, ems, wfms, maes = [], [], [], []
+    for p, t in zip(np.asarray(y_pred)[:, 0], np.asarray(y_true)[:, 0]):
+        pred, gt = prepare_data(p * 255, t * 255)
+        sms.append(sm(pred, gt))
+        ems.append(em_changeable(pred, gt))
+        wfms.append(wfm(pred, gt, beta=0.3))
+        maes.append(mae(pred, gt))
+    return (float(np.mean(np.array(sms, np.float64))), float(np.mean(np.array(ems, np.float64), axis=0).mean()),
+            float(np.mean(np.array(wfms, np.float64))), float(np.mean(np.array(maes, np.float64))))
 
 
 # ---- recorder/new_evaluator.py:47-59,68-71 --------------------------------------------------------------------------

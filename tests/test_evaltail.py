@@ -1,9 +1,11 @@
 """N2: the evaluation tail after the path.
 
-CPU: the per-pixel oracle (oracle/metrics_oracle.py) is pinned to the reference's own IOU and Classification classes
-through tests/golden/evaltail.npz (tools/make_evaltail_golden.py); the product's counter -> metric arithmetic
-(camouflaged_vlm_amd/evaltail.py) is checked against the oracle on counters built with numpy.
-GPU: the HIP kernels -- mask -> uint8, joint histograms (bit-exact integer work), top-k counters -- through the C ABI."""
+CPU: the per-pixel oracle (oracle/metrics_oracle.py) is pinned to the reference's own classes -- `OVCOSMetricer` with all six
+metric classes over the in-tree recorder/sod_metric.py, `utils.calc_cod`, `Classification` -- through tests/golden/evaltail.npz
+(tools/make_evaltail_golden.py drives the real reference code); the product's counter -> metric arithmetic
+(camouflaged_vlm_amd/evaltail.py) is checked against the same reference vectors on counters built with numpy.
+GPU: the HIP kernels -- mask -> uint8, joint histograms (bit-exact integer work), weighted F-measure, top-k counters --
+through the C ABI, against the reference vectors."""
 import os
 
 import numpy as np
@@ -47,13 +49,49 @@ def _close(a, b, tag):
     assert np.allclose(a, b, rtol=0, atol=TOL, equal_nan=True), (tag, float(np.nanmax(np.abs(a - b))))
 
 
-def test_oracle_iou_matches_reference_golden(gold):
+METRIC_KEYS = ("sm", "wfm", "mae", "fm_adp", "fm_curve", "em_adp", "em_curve", "iou_adp", "iou_curve")
+SHOW_KEYS = ("sm", "wfm", "mae", "adpfm", "maxfm", "avgfm", "adpem", "maxem", "avgem", "adpiou", "maxiou", "avgiou")
+
+
+def _ref(gold, i, same, k):
+    return gold[f"case{i}_{'same' if same else 'diff'}_{k}"]
+
+
+def test_oracle_matches_reference_metricer_per_image(gold):
+    """every value one `OVCOSMetricer.step` records (Sm, wFm, MAE, adaptive + 256-point F / E / IoU), bit for bit"""
     for i, pre, gt in _cases(gold):
         for same in (True, False):
             got = M.ovcos_metrics(pre, gt, same)
-            tag = f"case{i}_{'same' if same else 'diff'}"
-            assert np.array_equal(np.asarray(got["iou_curve"], dtype=np.float64), gold[f"{tag}_curve"]), tag
-            assert float(got["iou_adp"]) == float(gold[f"{tag}_adp"][0]), tag
+            assert set(got) == set(METRIC_KEYS)
+            for k in METRIC_KEYS:
+                assert np.array_equal(np.asarray(got[k], dtype=np.float64).reshape(-1), _ref(gold, i, same, k)), (i, same, k)
+
+
+def test_oracle_aggregate_matches_reference_show(gold):
+    steps = [M.ovcos_metrics(gold[f"case{i}_pre"], gold[f"case{i}_gt"], bool(s)) for i, s in gold["show_sequence"]]
+    agg = M.aggregate(steps)
+    assert tuple(agg) == SHOW_KEYS or set(agg) == set(SHOW_KEYS)
+    for k, raw, shown in zip(SHOW_KEYS, gold["show_raw"], gold["show_rounded"]):
+        assert agg[k] == raw, (k, agg[k], raw)
+        assert np.float64(agg[k]).round(3) == shown, k
+
+
+def test_oracle_calc_cod_matches_reference(gold):
+    """utils.py:143-165 on float probability maps (no uint8 step), batch of 4 and one image at a time"""
+    pred, gt = gold["cod_pred"], gold["cod_gt"].astype(np.float32)
+    assert list(M.calc_cod(pred, gt)) == gold["cod_result"].tolist()
+    for k in range(len(pred)):
+        assert list(M.calc_cod(pred[k:k + 1], gt[k:k + 1])) == gold["cod_per_image"][k].tolist(), k
+
+
+def test_counts_to_metrics_match_reference_metricer(gold):
+    """the product's host arithmetic (counters -> metrics) against the reference's per-pixel classes"""
+    for i, pre, gt in _cases(gold):
+        stats, hist = _counts_numpy(pre, gt)
+        for same in (True, False):
+            got = E.metrics_from_counts(stats, hist, *gt.shape, same_class=same)
+            for k in got:
+                _close(np.asarray(got[k], dtype=np.float64).reshape(-1), _ref(gold, i, same, k), (i, same, k))
 
 
 def test_oracle_classification_matches_reference_golden(gold):
@@ -200,21 +238,36 @@ def test_wfm_batched_full_size():
 
 
 @pytest.mark.gpu
-def test_device_metricer_end_to_end(gold):
-    names = ["a", "b"]
-    m = E.DeviceMetricer(names)
-    steps = []
+def test_device_per_image_matches_reference_metricer(gold):
+    """HIP counters + weighted-F sums -> every per-image value of the reference's six metric classes"""
     for i, pre, gt in _cases(gold):
-        same = i % 3 != 0
-        m.step(_dev(pre), _dev(gt), same)
-        steps.append(M.ovcos_metrics(pre, gt, same))
-    want = M.aggregate(steps)
+        p, g = _dev(pre)[None], _dev(gt)[None]
+        stats, hist = E.mask_counts(p, g)
+        wsum = E.mask_wfm_sums(p, g, hist)[0].cpu().numpy()
+        for same in (True, False):
+            got = E.metrics_from_counts(stats[0].cpu().numpy(), hist[0].cpu().numpy(), *gt.shape, same_class=same,
+                                        metric_names=E.SUPPORTED, wfm_sums=wsum)
+            assert set(got) == set(METRIC_KEYS)
+            for k in METRIC_KEYS:
+                _close(np.asarray(got[k], dtype=np.float64).reshape(-1), _ref(gold, i, same, k), (i, same, k))
+
+
+@pytest.mark.gpu
+def test_device_metricer_end_to_end(gold):
+    """`DeviceMetricer.step / get_step_results / show` against the reference's `OVCOSMetricer` fed the same sequence"""
+    m = E.DeviceMetricer(["a", "b"])
+    steps = []
+    for i, same in gold["show_sequence"].tolist():
+        m.step(_dev(gold[f"case{i}_pre"]), _dev(gold[f"case{i}_gt"]), bool(same))
+        steps.append(M.ovcos_metrics(gold[f"case{i}_pre"], gold[f"case{i}_gt"], bool(same)))
     got = m.get_step_results()
-    assert set(got) == set(want)
-    for k in want:
-        assert abs(float(got[k]) - want[k]) < TOL, (k, float(got[k]), want[k])
+    assert set(got) == set(SHOW_KEYS)
+    for k, raw in zip(SHOW_KEYS, gold["show_raw"]):
+        assert abs(float(got[k]) - raw) < TOL, (k, float(got[k]), raw)
     shown = m.show()
-    assert all(abs(shown[k] - round(want[k], 3)) < 1e-12 for k in want)
+    assert [shown[k] for k in SHOW_KEYS] == gold["show_rounded"].tolist()
+    want = M.aggregate(steps)                                  # and the oracle agrees with both
+    assert all(abs(float(got[k]) - want[k]) < TOL for k in want)
 
 
 @pytest.mark.gpu
