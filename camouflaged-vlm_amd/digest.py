@@ -32,7 +32,8 @@ def n_images(dg: Dict[str, np.ndarray]) -> int:
 def check_cascade(masks, pred, logits, dg: Dict[str, np.ndarray], image_ids: Sequence[int],
                   pass1_logits=None) -> dict:
     """masks (B,1,S,S) mask logits, pred (B,), logits (B,n_cls) of images `image_ids` (indices into the digest; ids the
-    digest does not hold are skipped).  Returns the worst figures over the checked images and `ok`."""
+    digest does not hold are skipped).  Returns the worst figures over the checked images and `ok`; when NO image could be
+    checked `ok` is None (neither pass nor fail: a caller that tests `r["ok"]` alone must not read that as verified)."""
     m = masks.detach().float().cpu().numpy()
     lg = logits.detach().float().cpu().numpy()
     pr = pred.detach().cpu().numpy()
@@ -55,7 +56,7 @@ def check_cascade(masks, pred, logits, dg: Dict[str, np.ndarray], image_ids: Seq
         per.append(rec)
         checked.append(int(iid))
     if not per:
-        return {"checked_images": [], "ok": True}
+        return {"checked_images": [], "ok": None}
     out = {"checked_images": checked, "min_iou": min(r["iou"] for r in per),
            "max_abs_mask_err": max(r["mask_err"] for r in per), "max_abs_class_logit_err": max(r["logit_err"] for r in per),
            "pred_equal": all(r["pred_equal"] for r in per), "tolerance": TOL, "iou_min": IOU_MIN}
@@ -83,7 +84,7 @@ def check_features(feats, grid: int, dg: Dict[str, np.ndarray], image_ids: Seque
         cms.append(float(np.abs(nchw.mean(axis=(1, 2)) - dg[cmean_key][iid]).max()))
         checked.append(int(iid))
     if not errs:
-        return {"checked_images": [], "ok": True}
+        return {"checked_images": [], "ok": None}
     return {"checked_images": checked, "max_abs_feature_err": max(errs), "max_abs_channel_mean_err": max(cms), "tolerance": TOL,
             "ok": bool(max(errs) <= TOL and max(cms) <= TOL)}
 

@@ -100,7 +100,7 @@ class Linear:
     """Packed weight of one NT GEMM: rows scaled by a power of two so the lo plane stays in fp16's
     normal range, K zero-padded to a multiple of 32, optional N padding (zero rows)."""
 
-    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device, n_pad: int = 0, k_pad: int = 0):
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device, n_pad: int = 0, k_pad: int = 0, il: bool = True):
         w = w.detach().float().reshape(w.shape[0], -1).cpu()
         N, K = w.shape
         self.N = max(N, n_pad)
@@ -113,8 +113,9 @@ class Linear:
         self.alpha = float(2.0 ** (-e))
         self.w = H2(H2.pack(wp * (2.0 ** e)).t.to(device))
         # second image with the planes interleaved per 32 k-elements (cvlm_gemm_args.w_il, ABI 6): what the big-tile kernels stage
-        # the weight from; small matrices never reach those kernels
-        self.w_il = hip.interleave_planes(self.w) if self.N * self.K >= (1 << 18) and os.environ.get("CVLM_GEMM_WIL", "1") == "1" else None
+        # the weight from; small matrices never reach those kernels, and `il=False` marks weights that only the tap / fallback
+        # schedules launch (the unfused twins of LayerNorm-folded GEMMs): they stay planar and cost no second copy
+        self.w_il = hip.interleave_planes(self.w) if il and self.N * self.K >= (1 << 18) and os.environ.get("CVLM_GEMM_WIL", "1") == "1" else None
         self.bias = None
         if b is not None:
             bp = torch.zeros(self.N)
@@ -214,13 +215,17 @@ class SamEncoder(_Base):
         # LayerNorm folded into the GEMMs that consume it + the residual stream kept in h2 between them: no LayerNorm
         # kernels inside the blocks (64 launches, 4.5 ms per step at B = 8).  CVLM_LN_FOLD=0 restores the separate passes.
         self.ln_fold = os.environ.get("CVLM_LN_FOLD", "1") == "1"
+        self.fold_disabled = False          # set by Cascade's refusal guard: rows with |mu|/sigma > 128 met -> separate LayerNorm passes
         self.blocks = []
         for i in range(g.depth):
             b = f"blocks.{i}."
             blk = dict(
                 n1w=self.dev(sd[P + b + "norm1.weight"]), n1b=self.dev(sd[P + b + "norm1.bias"]),
                 n2w=self.dev(sd[P + b + "norm2.weight"]), n2b=self.dev(sd[P + b + "norm2.bias"]),
-                qkv=L(b + "attn.qkv"), proj=L(b + "attn.proj"), lin1=L(b + "mlp.lin1"), lin2=L(b + "mlp.lin2"),
+                # with the fold on, qkv / lin1 (and lin2 of every block but the last: lin2cat carries it) are launched by the tap
+                # schedule and the refusal fallback only: planar, no 128-byte-row image (~1 GB at ViT-H)
+                qkv=L(b + "attn.qkv", il=not self.ln_fold), proj=L(b + "attn.proj"), lin1=L(b + "mlp.lin1", il=not self.ln_fold),
+                lin2=L(b + "mlp.lin2", il=not self.ln_fold or i == g.depth - 1),
                 pad=H2(H2.pack(sd[P + b + "attn.qkv.bias"].detach().float().cpu()).t.to(device)),
                 rel_h=H2(H2.pack(sd[P + b + "attn.rel_pos_h"].detach().float().cpu()).t.to(device)),
                 rel_w=H2(H2.pack(sd[P + b + "attn.rel_pos_w"].detach().float().cpu()).t.to(device)),
@@ -271,6 +276,15 @@ class SamEncoder(_Base):
         `out_name` (a caller that keeps two batches in flight alternates two names)."""
         self._out_name = out_name
         self._issue_hook = issue_hook
+        try:
+            feats = self._forward(inp, taps)
+            if self._issue_hook is not None:                         # never fired (cannot happen for depth >= 1): run it now
+                self._hook(self.g.depth)
+            return feats
+        finally:
+            self._issue_hook = None                                  # an exception before block 5 must not leave a stale hook behind
+
+    def _forward(self, inp: torch.Tensor, taps: Optional[dict]) -> torch.Tensor:
         g, ws, pr = self.g, self.ws, self.prec
         B = inp.shape[0]
         assert inp.shape[1:] == (3, g.inp_size, g.inp_size), \
@@ -309,7 +323,7 @@ class SamEncoder(_Base):
         hid = ws.h2("hid", M, HK)
         hid_prm = H2(hid.t[:, :, g.mlp_dim:])                      # the PK trailing columns (same row pitch)
         fold = taps is None                                        # block taps need x before the next prompt is added
-        if fold and self.ln_fold:
+        if fold and self.ln_fold and not self.fold_disabled:
             return self._blocks_folded(x, feat, prm, qkv, att, hid, hid_prm, B)
         for i, blk in enumerate(self.blocks):
             # :138/:145 prompt_i = shared_mlp(GELU(lightweight_mlp_i(feat))) ; x = prompt_i + x
@@ -364,7 +378,8 @@ class SamEncoder(_Base):
         # weights.  Block 0 reads the planar seed that cvlm_row_stats_split wrote and its proj writes the image; the attention
         # output stays in planes (the attention kernels write it).
         use_il = ((M > 4096 or self.act_il_small) and self.act_il and pr.gemm == 3 and D % 32 == 0 and HK % 32 == 0 and self.neck0.w_il is not None and
-                  all(b["qkv_f"].w_il is not None and b["lin1_f"].w_il is not None and b["lin2"].w_il is not None for b in self.blocks))
+                  all(b["qkv_f"].w_il is not None and b["lin1_f"].w_il is not None for b in self.blocks) and
+                  self.blocks[-1]["lin2"].w_il is not None and all(l.w_il is not None for l in self.lin2cat))
         xo = xh                                                      # where proj / lin2 write the stream
         if use_il:
             xo = ws.h2il("xh_il", M, D)
@@ -762,6 +777,7 @@ class ClipModel(_Base):
         # vision tower with ln_1 / ln_2 folded into in_proj / c_fc and the residual stream in h2 (as the SAM blocks, §4):
         # CVLM_CLIP_LN_FOLD=0 keeps the separate LayerNorm passes (the text tower, run once, always does)
         self.ln_fold = os.environ.get("CVLM_CLIP_LN_FOLD", "1") == "1" and c.vision_width % 8 == 0
+        self.fold_disabled = False          # as SamEncoder.fold_disabled
         if self.ln_fold:
             for i, blk in enumerate(self.vblocks):
                 p = f"{ie}transformer.resblocks.{i}."
@@ -864,7 +880,7 @@ class ClipModel(_Base):
         x = ws.f32("cx", B, L, Wd)
         hip.clip_assemble(pe, self.cls, self.pos, self.shared_ctx, B, P, Wd, c.n_ctx, x)
         hip.layernorm(x, *self.ln_pre, 1e-5, B * L, Wd, out_f32=x)
-        if self.ln_fold:
+        if self.ln_fold and not self.fold_disabled:
             cls = self._vision_blocks_folded(x, B, L, Wd, c.vision_heads, L - c.n_ctx)
         else:
             self._blocks(x, self.vblocks, B, L, Wd, c.vision_heads, self.deep_vis, L - c.n_ctx, causal=False)
@@ -957,9 +973,49 @@ class Cascade(_Base):
         self.encoder_first = os.environ.get("CVLM_ENCODER_FIRST", "1") == "1"
         self._pending = None                                         # (masks, clip_image, pred, logits) of the batch whose stage 2 is still owed
         self._pending_stream = None
+        self._clip_done = None                                       # end of the last fused CLIP forward (reader of the owned input copies)
         self._side = None
         self._done = [None, None]                                    # side-stream completion events of the last two batches
         self._parity = 0
+        self._guard, self._guard_host, self._refused_seen, self.fold_refusals = None, None, 0, 0
+
+    # ---- LayerNorm-fold refusal guard ---------------------------------------------------------------------------
+    # A row with |mu| / sigma > 128 cannot be served by the folded LayerNorm within the error budget:
+    # cvlm_ln_stats_merge writes NaN for it and counts it in word 513 of the GEMM workspace -- a NaN mask, never a finite wrong
+    # one.  The reference's nn.LayerNorm serves such rows, so the product must not keep returning NaN: after every forward the
+    # two counters (encoder, CLIP tower) are copied to pinned host memory asynchronously (no synchronisation on the path); the
+    # next call that finds the copy complete and a counter raised switches BOTH towers to the separate two-pass LayerNorm
+    # schedule for the rest of the model's life and says so.  The batch that met the rows has NaN outputs (loud); every later
+    # batch is served.
+    def _fold_guard_check(self) -> None:
+        g = self._guard
+        if g is None or not g[1].query():
+            return
+        self._guard = None
+        refused = int(g[0][0]) + int(g[0][1])
+        if refused > self._refused_seen:
+            self._refused_seen = refused
+            self.fold_refusals = refused
+            self.encoder.fold_disabled = True
+            self.clip.fold_disabled = True
+            import warnings
+            warnings.warn(f"camouflaged_vlm_amd: {refused} token row(s) with |mean| / std > 128 were refused by the folded LayerNorm "
+                          "(their images came out NaN); switching to the separate LayerNorm passes from this batch on "
+                          "(set CVLM_LN_FOLD=0 CVLM_CLIP_LN_FOLD=0 to start that way)", RuntimeWarning, stacklevel=3)
+
+    def _fold_guard_arm(self, stream) -> None:
+        if not ((self.encoder.ln_fold and not self.encoder.fold_disabled) or (self.clip.ln_fold and not self.clip.fold_disabled)):
+            return
+        if self._guard_host is None:
+            self._guard_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        with torch.cuda.stream(stream):
+            for k, eng in enumerate((self.encoder, self.clip)):
+                w = eng.ws._gemm_ws
+                if w is not None:
+                    self._guard_host[k:k + 1].copy_(w[2052:2056].view(torch.int32), non_blocking=True)   # word 513
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._guard = (self._guard_host, ev)
 
     def sparse_prompts(self, img_f: torch.Tensor, txt_f: torch.Tensor, B: int) -> torch.Tensor:
         """models/sam_maskdecoder_edge.py:342-344."""
@@ -978,6 +1034,7 @@ class Cascade(_Base):
 
     def infer_test(self, inp, clip_image, clip_mask, taps: Optional[dict] = None) -> torch.Tensor:
         self.flush()
+        self._fold_guard_check()
         g = self.g
         B = inp.shape[0]
         # CLIP pass 1 only needs (clip_image, clip_mask): it runs on a side stream underneath the SAM encoder so
@@ -1018,6 +1075,7 @@ class Cascade(_Base):
         hip.bilinear(low, B, 4 * g.grid, 4 * g.grid, masks, g.inp_size, g.inp_size)   # :380-387 (2nd resize = identity)
         if taps is not None:
             taps.update(features=feats.clone(), sparse=sparse.clone(), pass1_logits=score.clone())
+        self._fold_guard_arm(torch.cuda.current_stream())
         return masks
 
     def stage2(self, mask_logits: torch.Tensor, clip_image: torch.Tensor):
@@ -1033,11 +1091,17 @@ class Cascade(_Base):
         run on the side stream.
         pipelined=False: the current stream waits for the side stream before returning (plain stream semantics).
         pipelined=True: it does not -- the caller's next batch starts its encoder underneath this batch's decoder and
-        stage 2 (a serving loop: results are complete after `torch.cuda.synchronize()` or once the side stream has been
-        waited for; the next `cascade()` orders itself behind the previous one, at most one batch is in flight there)."""
+        stage 2 (a serving loop; the next `cascade()` orders itself behind the previous one, at most one batch is in flight
+        there).  CONTRACT of the pipelined loop (default form: CVLM_FUSE_CLIP=1, `_cascade_fused`): `masks` of a call are
+        complete after `torch.cuda.synchronize()`, but its `pred` / `logits` are OWED -- they are filled by the NEXT
+        `cascade(pipelined=True)` call or by `flush()`, then complete after the following synchronize.  A caller that stops
+        feeding batches MUST call `flush()`; until then `pred` holds -1 and `logits` NaN (sentinels, never stale data).
+        The inputs may be refilled in place as soon as the call has returned: `clip_image` / `clip_mask` are copied (on the
+        caller's stream) into buffers the engine owns before anything reads them later."""
         if pipelined and self.fuse_clip:
             return self._cascade_fused(inp, clip_image, clip_mask)
         self.flush()
+        self._fold_guard_check()
         if not self.overlap_clip:
             masks = self.infer_test(inp, clip_image, clip_mask)
             _, _, pred, logits = self.stage2(masks, clip_image)
@@ -1080,6 +1144,7 @@ class Cascade(_Base):
             _, _, pred, logits = self.stage2(masks, clip_image)
             done = torch.cuda.Event()
             done.record(side)
+        self._fold_guard_arm(side)
         self._done[self._parity] = done
         self._parity ^= 1
         for t in (inp, clip_image, clip_mask):
@@ -1094,9 +1159,11 @@ class Cascade(_Base):
         """pipelined=True with the two CLIP forwards of a step fused: this call launches, on the side stream, ONE vision-tower
         forward over [stage 2 of the PREVIOUS batch | pass 1 of this batch], then this batch's decoder behind its encoder; the
         stage 2 of this batch is owed until the next call -- or `flush()`, which a caller that stops feeding batches must
-        issue (bench.py does, inside the timed region).  The returned `pred` / `logits` tensors are filled by that later
-        launch; `masks` by this one.  cocotrainers/mapleAlphaCLIP.py:281-294 twice, demo.py:117-122."""
+        issue (bench.py does, inside the timed region).  The returned `pred` / `logits` tensors hold sentinels (-1 / NaN) until
+        that later launch fills them; `masks` is filled by this one.  cocotrainers/mapleAlphaCLIP.py:281-294 twice,
+        demo.py:117-122."""
         g, B = self.g, inp.shape[0]
+        self._fold_guard_check()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream()
@@ -1105,19 +1172,34 @@ class Cascade(_Base):
         if self._done[self._parity] is not None:                     # the batch before the previous one has left the side stream
             main.wait_event(self._done[self._parity])
         prev = self._pending
+        # The side stream reads clip_image / clip_mask now (pass 1) and clip_image again one call later (the owed stage 2): keep
+        # copies the engine owns, made on the caller's stream, so that a serving loop may refill its input buffers in place
+        # (ADVICE r3).  3.6 MB at B = 8; two buffers alternate with the batches in flight.
+        R = self.c.image_resolution
+        if self._clip_done is not None:                              # the forward that read these buffers two batches ago
+            main.wait_event(self._clip_done)                         # (it ran under the previous encoder: long finished)
+        own_image = self.ws.f32("own_clip_image%d" % self._parity, B, 3, R, R)
+        own_mask = self.ws.f32("own_clip_mask%d" % self._parity, B, 1, R, R)
+        own_image.copy_(clip_image)
+        own_mask.copy_(clip_mask)
+        clip_image, clip_mask = own_image, own_mask
 
         def clip_forwards():
-            if prev is None:
-                i_f, t_f, _, _ = self.clip.forward(clip_image, clip_mask)
-                return i_f, t_f
-            p_masks, p_image, p_pred, p_logits = prev
-            Bp, R = p_masks.shape[0], self.c.image_resolution
-            alpha = self.ws.f32("alpha2", Bp, 1, R, R)
-            hip.bilinear(p_masks, Bp, g.inp_size, g.inp_size, alpha, R, R, sigmoid_in=True)
-            img_n, sel, pred_all, logits_all = self.clip.forward([p_image, clip_image], [alpha, clip_mask])
-            p_pred.copy_(pred_all[:Bp])                              # results of the previous batch land in the tensors it returned
-            p_logits.copy_(logits_all[:Bp])
-            return img_n[Bp:], sel[Bp:]
+            try:
+                if prev is None:
+                    i_f, t_f, _, _ = self.clip.forward(clip_image, clip_mask)
+                    return i_f, t_f
+                p_masks, p_image, p_pred, p_logits = prev
+                Bp = p_masks.shape[0]
+                alpha = self.ws.f32("alpha2", Bp, 1, R, R)
+                hip.bilinear(p_masks, Bp, g.inp_size, g.inp_size, alpha, R, R, sigmoid_in=True)
+                img_n, sel, pred_all, logits_all = self.clip.forward([p_image, clip_image], [alpha, clip_mask])
+                p_pred.copy_(pred_all[:Bp])                          # results of the previous batch land in the tensors it returned
+                p_logits.copy_(logits_all[:Bp])
+                return img_n[Bp:], sel[Bp:]
+            finally:
+                self._clip_done = torch.cuda.Event()
+                self._clip_done.record(torch.cuda.current_stream())
 
         if self.encoder_first and side is not main:                  # see infer_test
             ready = torch.cuda.Event()
@@ -1147,14 +1229,16 @@ class Cascade(_Base):
             masks = torch.empty(B, 1, g.inp_size, g.inp_size, device=self.device)
             hip.bilinear(low, B, 4 * g.grid, 4 * g.grid, masks, g.inp_size, g.inp_size)
             n_cls = self.clip.txt["test"].shape[0]
-            pred = torch.empty(B, dtype=torch.int64, device=self.device)
-            logits = torch.empty(B, n_cls, device=self.device)
+            # owed until the next call / flush(): sentinels, so that a missing flush() reads as "not computed", never as data
+            pred = torch.full((B,), -1, dtype=torch.int64, device=self.device)
+            logits = torch.full((B, n_cls), float("nan"), device=self.device)
             done = torch.cuda.Event()
             done.record(side)
+        self._fold_guard_arm(side)
         self._done[self._parity] = done
         self._parity ^= 1
         self._pending = (masks, clip_image, pred, logits)
-        for t in (inp, clip_image, clip_mask):
+        for t in (inp,):
             t.record_stream(side)
         for t in (masks, pred, logits):
             t.record_stream(main)
@@ -1174,4 +1258,5 @@ class Cascade(_Base):
             p_logits.copy_(logits)
             done = torch.cuda.Event()
             done.record(side)
+        self._clip_done = done                                       # this forward read the owned copy of the batch's clip_image
         self._done[self._parity ^ 1] = done                          # the slot of the batch just completed

@@ -54,6 +54,15 @@ def _coeffs(in_size: int, out_size: int, filt: str) -> Tuple[np.ndarray, np.ndar
     return bounds, kk
 
 
+def clip_mask_value(convention: str = "wrapper") -> float:
+    """pass-1 alpha of an all-ones mask after alpha_clip.py:88-94 (Normalize(0.5, 0.26)): "wrapper" = (1 - 0.5) / 0.26 = 1.923
+    (uint8 mask, ToTensor divides by 255, wrappers.py:62); "demo" = (255 - 0.5) / 0.26 = 978.8 (demo.py:102-104: float64 array,
+    PIL mode 'F', which ToTensor does not rescale)."""
+    if convention not in ("wrapper", "demo"):
+        raise ValueError(f"unknown clip_mask convention {convention!r}")
+    return (1.0 - 0.5) / 0.26 if convention == "wrapper" else (255.0 - 0.5) / 0.26
+
+
 class GpuPreprocess:
     def __init__(self, inp_size: int = 1024, clip_size: int = 336, device="cuda"):
         self.S, self.R, self.device = inp_size, clip_size, torch.device(device)
@@ -107,10 +116,7 @@ class GpuPreprocess:
     def clip_mask(self, n: int, convention: str = "wrapper") -> torch.Tensor:
         """mask_transform on an all-ones mask: "wrapper" = (1 - 0.5) / 0.26 (uint8 mask, wrappers.py:62);
         "demo" = (255 - 0.5) / 0.26 (demo.py:103: float64 array, not rescaled by ToTensor)."""
-        if convention not in ("wrapper", "demo"):
-            raise ValueError(f"unknown clip_mask convention {convention!r}")
-        v = (1.0 - 0.5) / 0.26 if convention == "wrapper" else (255.0 - 0.5) / 0.26
-        return torch.full((n, 1, self.R, self.R), v, dtype=torch.float32, device=self.device)
+        return torch.full((n, 1, self.R, self.R), clip_mask_value(convention), dtype=torch.float32, device=self.device)
 
     def __call__(self, img: torch.Tensor):
         if img.dim() == 3:

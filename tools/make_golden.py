@@ -8,7 +8,7 @@ into the reference modules with ``load_state_dict(strict=True)`` (which is also 
 spec.py restates the reference's key layout exactly), and the reference's outputs are saved as
 small ``.npz`` fixtures under tests/golden/.
 
-Usage:  python tools/make_golden.py [--out tests/golden] [--demo-digest] [--only-demo-digest|--only-hires-digest [--images N] [--check]]
+Usage:  python tools/make_golden.py [--out tests/golden] [--demo-digest] [--only-tiny] [--only-demo-digest|--only-demo-alpha-digest|--only-hires-digest [--images N] [--check]]
 """
 from __future__ import annotations
 
@@ -71,6 +71,9 @@ def install_reference():
     with open(os.path.join(REF, "datasets/ovcamo_info/class_names.py")) as f:
         exec(f.read(), ns)
     return mm, ml, cm, ns["TRAIN_CLASS_NAMES"], ns["TEST_CLASS_NAMES"]
+
+
+DEMO_ALPHA = (255.0 - 0.5) / 0.26          # demo.py:102-104 through alpha_clip.py:88-94 (Normalize(0.5, 0.26), no /255)
 
 
 class DotDict:
@@ -172,8 +175,16 @@ def tiny(out_dir, mods):
     for h in hooks:
         h.remove()
     taps["edge_emb"] = taps.pop("maskfeature") + taps["edge_features"]
+    # demo.py:102-104 feeds pass 1 an alpha of (255 - 0.5) / 0.26 = 978.8 (a float64 all-255 PIL image is not rescaled by
+    # ToTensor): images 2 and 3 of the synthetic stream run with that value
+    inp_d, clip_image_d, _ = synth.make_inputs(g, c, batch=2, index0=2)
+    clip_mask_d = np.full((2, 1, c.image_resolution, c.image_resolution), DEMO_ALPHA, np.float32)
+    masks_d, preds_d, logits_d, logits1_d = run_reference(model, inp_d, clip_image_d, clip_mask_d, c.image_resolution)
     np.savez_compressed(
         os.path.join(out_dir, "tiny_cascade.npz"),
+        demoalpha_mask_logits=masks_d.astype(np.float32), demoalpha_pred=preds_d.astype(np.int64),
+        demoalpha_class_logits=logits_d.astype(np.float32), demoalpha_pass1_logits=logits1_d.astype(np.float32),
+        demoalpha_value=np.float32(DEMO_ALPHA),
         mask_logits=masks.astype(np.float32), pred=preds.astype(np.int64), class_logits=logits.astype(np.float32),
         pass1_logits=logits1.astype(np.float32), eot_train=eot_train, eot_test=eot_test,
         bank_test=model.test_text_features.numpy(), bank_train=model.train_text_features.numpy(),
@@ -245,6 +256,32 @@ def demo_digest(out_dir, mods, n_images=16, check=False):
         _check_prefix(path, out, n_images)
         return
     np.savez_compressed(path, ref_seconds=np.array(secs), threads=np.array(torch.get_num_threads()), **out)
+
+
+def demo_alpha_digest(out_dir, mods, n_images=1, check=False):
+    """BASELINE configs[0] IS demo.py: the full demo.yaml geometry with demo.py's own pass-1 alpha, (255 - 0.5) / 0.26 = 978.8
+    (demo.py:102-104), on images 0..n-1 of the synthetic stream (the inputs of demo_digest.npz; only the
+    alpha differs).  Same per-image arrays as `demo_digest`."""
+    mm, ml, cm, train_names, test_names = mods
+    g, c = spec.DEMO_SAM, spec.DEMO_CLIP
+    model, sd, eot_train, eot_test = build_reference(mm, ml, cm, g, c, train_names, test_names)
+    inp, clip_image, _ = synth.make_inputs(g, c, batch=n_images)
+    clip_mask = np.full((n_images, 1, c.image_resolution, c.image_resolution), DEMO_ALPHA, np.float32)
+    idx = np.random.default_rng(0).integers(0, inp.shape[2] * inp.shape[3], size=4096)
+    bits, samples, preds, logits, logits1 = [], [], [], [], []
+    for b in range(n_images):
+        m, p, s, s1 = run_reference(model, inp[b:b + 1], clip_image[b:b + 1], clip_mask[b:b + 1], c.image_resolution)
+        bits.append(np.packbits(m > 0)); samples.append(m.reshape(-1)[idx])
+        preds.append(p[0]); logits.append(s[0]); logits1.append(s1[0])
+        print("demo alpha: image %d; mask std %.3f; pred %s; pass-1 logits[:3] %s" % (b, m.std(), p, s1[0, :3]), flush=True)
+    out = dict(mask_bits=np.stack(bits), mask_samples=np.stack(samples).astype(np.float32), sample_idx=idx,
+               pred=np.array(preds, np.int64), class_logits=np.stack(logits).astype(np.float32),
+               pass1_logits=np.stack(logits1).astype(np.float32), eot_test=eot_test, alpha=np.float32(DEMO_ALPHA))
+    path = os.path.join(out_dir, "demo_alpha_digest.npz")
+    if check:
+        _check_prefix(path, out, n_images)
+        return
+    np.savez_compressed(path, **out)
 
 
 def _check_prefix(path, out, n):
@@ -448,6 +485,8 @@ if __name__ == "__main__":
     ap.add_argument("--only-n3", action="store_true")
     ap.add_argument("--skip-tiny", action="store_true")
     ap.add_argument("--only-demo-digest", action="store_true")
+    ap.add_argument("--only-demo-alpha-digest", action="store_true")
+    ap.add_argument("--only-tiny", action="store_true")
     ap.add_argument("--images", type=int, default=None,
                     help="digest runs: number of images (default 16 for the demo digest, 4 for the 1536^2 digest)")
     ap.add_argument("--check", action="store_true",
@@ -470,6 +509,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if args.only_demo_digest:
         demo_digest(args.out, mods, args.images or 16, args.check)
+        sys.exit(0)
+    if args.only_demo_alpha_digest:
+        demo_alpha_digest(args.out, mods, args.images or 1, args.check)
+        sys.exit(0)
+    if args.only_tiny:
+        tiny(args.out, mods)
         sys.exit(0)
     tokens(args.out, mods)
     if not args.skip_tiny:
