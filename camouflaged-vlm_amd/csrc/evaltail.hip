@@ -196,8 +196,60 @@ __global__ __launch_bounds__(256) void wfm_levels_kernel(const unsigned* __restr
     if (v == 0) { lohi[2 * n] = lo; lohi[2 * n + 1] = hi; }
 }
 
-// one thread per column: nearest foreground row above-or-at and below, ties to the smaller row
-__global__ __launch_bounds__(256) void wfm_colpass_kernel(const uint8_t* __restrict__ gt, int h, int w, int* __restrict__ near_y) {
+// Column pass: nearest foreground row inside each column (above-or-at vs below, ties to the smaller row).
+// A workgroup owns 64 columns; the column is cut into segments of 64 rows and a thread keeps the foreground flags of a
+// segment as one 64-bit mask (segments s = ty, ty + 16, ...: h <= 4096).  First / last foreground row of every segment go
+// through LDS; a row's answer is then two bit scans of its own mask plus the carries of the neighbouring segments -- the
+// column is read once, coalesced, by 16 segments at a time (round 3: one thread walked its whole column twice, 540 us at
+// 1365 x 2048: 32 waves on the whole chip waiting for one global load after the other).
+constexpr int WFM_SEG = 64, WFM_MAXSEG = 64;
+__global__ __launch_bounds__(1024) void wfm_colpass_kernel(const uint8_t* __restrict__ gt, int h, int w, int* __restrict__ near_y) {
+    __shared__ int first[WFM_MAXSEG][64], last[WFM_MAXSEG][64];
+    const int n = blockIdx.y, tx = threadIdx.x, ty = threadIdx.y;
+    const int x = blockIdx.x * 64 + tx;
+    const int S = (h + WFM_SEG - 1) / WFM_SEG;
+    const uint8_t* g = gt + (int64_t)n * h * w;
+    int* ny = near_y + (int64_t)n * h * w;
+    unsigned long long mask[WFM_MAXSEG / 16];
+#pragma unroll
+    for (int k = 0; k < WFM_MAXSEG / 16; ++k) {
+        const int sgm = ty + 16 * k;
+        unsigned long long m = 0;
+        if (sgm < S && x < w) {
+            const int y0 = sgm * WFM_SEG, cnt = min(WFM_SEG, h - y0);
+            for (int r = 0; r < cnt; ++r) m |= (unsigned long long)(g[(int64_t)(y0 + r) * w + x] > 128) << r;
+        }
+        mask[k] = m;
+        if (sgm < S) {
+            first[sgm][tx] = m ? sgm * WFM_SEG + __builtin_ctzll(m) : -1;
+            last[sgm][tx] = m ? sgm * WFM_SEG + 63 - __builtin_clzll(m) : -1;
+        }
+    }
+    __syncthreads();
+    if (x >= w) return;
+#pragma unroll
+    for (int k = 0; k < WFM_MAXSEG / 16; ++k) {
+        const int sgm = ty + 16 * k;
+        if (sgm >= S) continue;
+        int ca = -1, cb = -1;                                         // nearest foreground row in the segments above / below
+        for (int t = sgm - 1; t >= 0 && ca < 0; --t) ca = last[t][tx];
+        for (int t = sgm + 1; t < S && cb < 0; ++t) cb = first[t][tx];
+        const unsigned long long m = mask[k];
+        const int y0 = sgm * WFM_SEG, cnt = min(WFM_SEG, h - y0);
+        for (int r = 0; r < cnt; ++r) {
+            const int y = y0 + r;
+            const unsigned long long lo = m & (~0ull >> (63 - r)), hi = m >> r;
+            const int above = lo ? y0 + 63 - __builtin_clzll(lo) : ca;
+            const int below = hi ? y + __builtin_ctzll(hi) : cb;
+            int best = above;
+            if (below >= 0 && (above < 0 || below - y < y - above)) best = below;
+            ny[(int64_t)y * w + x] = best;
+        }
+    }
+}
+
+// the same for columns taller than WFM_SEG * WFM_MAXSEG rows: one thread per column
+__global__ __launch_bounds__(256) void wfm_colpass_tall_kernel(const uint8_t* __restrict__ gt, int h, int w, int* __restrict__ near_y) {
     const int n = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= w) return;
     const uint8_t* g = gt + (int64_t)n * h * w;
@@ -217,37 +269,67 @@ __global__ __launch_bounds__(256) void wfm_colpass_kernel(const uint8_t* __restr
     }
 }
 
-// one workgroup per row: Et[y][x] = E at the nearest foreground pixel (E itself on the foreground), d2 = squared distance
+// Row pass, one workgroup per row: Et[y][x] = E at the nearest foreground pixel (E itself on the foreground), d2 = squared
+// distance.  Only columns that hold foreground at all can be nearest (near_y >= 0, the same set for every row): the row's
+// candidates are compacted into LDS (column, dy^2), `rank[x]` = candidates left of x.  A background pixel scans the
+// candidates outwards from its own position, left side first, and stops a side once dx^2 alone exceeds the best distance --
+// the same minimum as the full scan in column order, ties to the smaller column: on the left a later (smaller) column
+// replaces an equal distance, on the right only a strictly smaller one does (round 3 scanned all w columns for every pixel).
 __global__ __launch_bounds__(256) void wfm_rowpass_kernel(const uint8_t* __restrict__ pre, const uint8_t* __restrict__ gt, int h,
                                                           int w, const int* __restrict__ near_y, const int* __restrict__ lohi,
                                                           int* __restrict__ d2o, double* __restrict__ Et) {
-    extern __shared__ int rowbuf[];                                   // dy^2 [w] | near row [w]
-    int* dy2 = rowbuf;
-    int* nry = rowbuf + w;
-    const int n = blockIdx.y, y = blockIdx.x;
+    extern __shared__ int rowbuf[];                                   // candidate column [w] | its dy^2 [w] | its near row [w] | rank [w]
+    __shared__ int wave_tot[4], total_c;
+    int* colx = rowbuf;
+    int* dy2 = rowbuf + w;
+    int* nry = rowbuf + 2 * w;
+    int* rank = rowbuf + 3 * w;
+    const int n = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)n * h * w;
     const int lo = lohi[2 * n], hi = lohi[2 * n + 1];
-    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+    // compaction: thread t owns the columns [t * per, t * per + per)
+    const int per = (w + 255) / 256;
+    const int c0 = min(tid * per, w), c1 = min(c0 + per, w);
+    int mine = 0;
+    for (int x = c0; x < c1; ++x) mine += near_y[base + (int64_t)y * w + x] >= 0;
+    int incl = mine;                                                  // inclusive scan over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int off = incl - mine;
+    for (int k = 0; k < wv; ++k) off += wave_tot[k];
+    if (tid == 255) total_c = off + mine;
+    for (int x = c0; x < c1; ++x) {
         const int r = near_y[base + (int64_t)y * w + x];
-        nry[x] = r;
-        dy2[x] = r < 0 ? WFM_INF : (r - y) * (r - y);
+        rank[x] = off;
+        if (r >= 0) { colx[off] = x; dy2[off] = (r - y) * (r - y); nry[off] = r; ++off; }
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < w; x += blockDim.x) {
+    const int cnt = total_c;
+    for (int x = tid; x < w; x += 256) {
         const int64_t i = base + (int64_t)y * w + x;
         if (gt[i] > 128) {
             d2o[i] = 0;
             Et[i] = fabs(wfm_norm(pre[i], lo, hi) - 1.0);
             continue;
         }
-        int best = WFM_INF + WFM_INF, bx = 0;
-        for (int xp = 0; xp < w; ++xp) {
-            const int d = (x - xp) * (x - xp) + dy2[xp];
-            if (d < best) { best = d; bx = xp; }                      // strict: ties keep the smaller column
+        int best = WFM_INF + WFM_INF, bj = -1;
+        const int p = rank[x];
+        for (int j = p - 1; j >= 0; --j) {                            // left of x, nearest column first
+            const int dx = x - colx[j], dd = dx * dx;
+            if (dd > best) break;
+            const int d = dd + dy2[j];
+            if (d <= best) { best = d; bj = j; }
+        }
+        for (int j = p; j < cnt; ++j) {                               // x itself and right of it
+            const int dx = colx[j] - x, dd = dx * dx;
+            if (dd >= best) break;
+            const int d = dd + dy2[j];
+            if (d < best) { best = d; bj = j; }
         }
         d2o[i] = best;
-        const int by = nry[bx];
-        Et[i] = by < 0 ? 0.0 : fabs(wfm_norm(pre[base + (int64_t)by * w + bx], lo, hi) - 1.0);
+        Et[i] = bj < 0 ? 0.0 : fabs(wfm_norm(pre[base + (int64_t)nry[bj] * w + colx[bj]], lo, hi) - 1.0);
     }
 }
 
@@ -381,9 +463,15 @@ int cvlm_mask_wfm(const uint8_t* pre, const uint8_t* gt, int32_t N, int32_t h, i
     int* lohi = (int*)(partial + (size_t)N * nparts * 3);
     hipLaunchKernelGGL(wfm_levels_kernel, dim3(N), dim3(256), 0, st, (const unsigned*)hist, lohi);
     CVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wfm_colpass_kernel, dim3((w + 255) / 256, N), dim3(256), 0, st, gt, h, w, near_y);
+    if (h <= WFM_SEG * WFM_MAXSEG)
+        hipLaunchKernelGGL(wfm_colpass_kernel, dim3((w + 63) / 64, N), dim3(64, 16), 0, st, gt, h, w, near_y);
+    else
+        hipLaunchKernelGGL(wfm_colpass_tall_kernel, dim3((w + 255) / 256, N), dim3(256), 0, st, gt, h, w, near_y);
     CVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wfm_rowpass_kernel, dim3(h, N), dim3(256), 2 * w * sizeof(int), st, pre, gt, h, w, (const int*)near_y,
+    const int smem_row = 4 * w * (int)sizeof(int);                   // 128 KB at the widest supported row (w = 8192)
+    if (smem_row > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)wfm_rowpass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_row);
+    hipLaunchKernelGGL(wfm_rowpass_kernel, dim3(h, N), dim3(256), smem_row, st, pre, gt, h, w, (const int*)near_y,
                        (const int*)lohi, d2, Et);
     CVLM_CHECK_LAUNCH();
     hipLaunchKernelGGL(wfm_weight_kernel, dim3(nparts, N), dim3(256), 0, st, pre, gt, h, w, (const int*)lohi, (const int*)d2,

@@ -233,17 +233,19 @@ class DeviceMetricer:
     def step_batch(self, logits: torch.Tensor, gts: Sequence[torch.Tensor], same_class) -> List[torch.Tensor]:
         """logits (B,1,H,W) f32 mask logits; gts: B uint8 (h_i,w_i) device tensors (ragged sizes allowed);
         same_class: B bools or a bool tensor (predicted class == ground-truth class).  Returns the uint8 masks."""
-        flags = same_class.tolist() if isinstance(same_class, torch.Tensor) else list(same_class)
+        # a device tensor of flags stays on the device until `show()` (no host synchronisation inside the loop)
+        flags = same_class if isinstance(same_class, torch.Tensor) else list(same_class)
         masks = []
         for i, gt in enumerate(gts):
             h, w = int(gt.shape[-2]), int(gt.shape[-1])
             pre = mask_to_u8(logits[i:i + 1], h, w)
-            self.step(pre[0], gt, bool(flags[i]))
+            self.step(pre[0], gt, flags[i] if isinstance(flags, torch.Tensor) else bool(flags[i]))
             masks.append(pre[0])
         return masks
 
-    def step(self, pre: torch.Tensor, gt: torch.Tensor, same_class: bool = True, gt_path: Optional[str] = None):
-        """pre / gt uint8 (h,w) device tensors (ovcos_metricer.py:269-272 takes numpy arrays and two class names)."""
+    def step(self, pre: torch.Tensor, gt: torch.Tensor, same_class=True, gt_path: Optional[str] = None):
+        """pre / gt uint8 (h,w) device tensors (ovcos_metricer.py:269-272 takes numpy arrays and two class names);
+        same_class: bool, or a 0-d device tensor (read at `show()` time)."""
         assert pre.shape == gt.shape, (tuple(pre.shape), tuple(gt.shape), gt_path)
         assert pre.dtype == gt.dtype == torch.uint8, (pre.dtype, gt.dtype, gt_path)
         if not pre.is_cuda:
@@ -251,7 +253,8 @@ class DeviceMetricer:
         p3, g3 = pre.reshape(1, *pre.shape[-2:]), gt.reshape(1, *gt.shape[-2:])
         stats, hist = mask_counts(p3, g3)
         wsum = mask_wfm_sums(p3, g3, hist) if "wfm" in self.metric_names else None
-        self._pending.append((stats, hist, int(pre.shape[-2]), int(pre.shape[-1]), bool(same_class), wsum))
+        flag = same_class.reshape(1).to(torch.bool) if isinstance(same_class, torch.Tensor) else bool(same_class)
+        self._pending.append((stats, hist, int(pre.shape[-2]), int(pre.shape[-1]), flag, wsum))
 
     def _drain(self) -> None:
         if not self._pending:
@@ -259,7 +262,10 @@ class DeviceMetricer:
         stats = torch.cat([p[0] for p in self._pending]).cpu().numpy()
         hist = torch.cat([p[1] for p in self._pending]).cpu().numpy()
         wsums = torch.cat([p[5] for p in self._pending]).cpu().numpy() if "wfm" in self.metric_names else None
+        dev_flags = [p[4] for p in self._pending if isinstance(p[4], torch.Tensor)]
+        dev_flags = iter(torch.cat(dev_flags).cpu().tolist()) if dev_flags else iter(())
         for i, (_, _, h, w, same, _) in enumerate(self._pending):
+            same = bool(next(dev_flags)) if isinstance(same, torch.Tensor) else same
             self._steps.append(metrics_from_counts(stats[i], hist[i], h, w, same, self.metric_names,
                                                    None if wsums is None else wsums[i]))
         self._pending = []

@@ -32,6 +32,22 @@ def test_oracle_resample_matches_pillow_golden(gold):
         assert np.array_equal(got, gold[f"out_{name}"]), name
 
 
+def test_host_coefficient_tables_equal_the_pillow_pinned_oracle():
+    """the product's vectorised table builder (camouflaged_vlm_amd.preprocess._coeffs: all output indices at once, the window sum
+    still left to right) against the oracle's per-index restatement of Pillow's precompute_coeffs / normalize_coeffs_8bpc:
+    bounds and 22-bit fixed-point taps, bit for bit -- up- and down-scaling, sizes of 1-3 pixels, both filters"""
+    from camouflaged_vlm_amd import preprocess as G
+    rng = np.random.default_rng(0)
+    cases = [(1920, 1024), (1080, 1024), (2048, 336), (1365, 336), (600, 1024), (1024, 1024), (337, 336), (5000, 336), (7, 1024),
+             (1024, 7), (3, 2), (2, 3), (1, 5), (5, 1)] + [(int(a), int(b)) for a, b in rng.integers(1, 2500, (40, 2))]
+    for n_in, n_out in cases:
+        for filt in ("bilinear", "bicubic"):
+            b, k = G._coeffs(n_in, n_out, filt)
+            ob, ok, ks = P.precompute_coeffs(n_in, n_out, filt)
+            assert k.shape == (n_out, ks) and b.dtype == np.int32 and k.dtype == np.int32
+            assert np.array_equal(b, np.asarray(ob).reshape(b.shape)) and np.array_equal(k, np.asarray(ok).reshape(k.shape)), (n_in, n_out, filt)
+
+
 def test_oracle_full_size_checksums(gold):
     big = _big(gold)
     assert zlib.crc32(big.tobytes()) == int(gold["big_crc"][0])
