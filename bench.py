@@ -786,8 +786,6 @@ def main():
         """demo.py:78-89 / test_ovcos_maskdecoder_edge.py:165-176: the model through the reference's own construction calls"""
         import models
         from cocotrainers.mapleAlphaCLIP import CustomCLIP
-        if args.no_overlap:
-            os.environ["CVLM_OVERLAP_CLIP"] = "0"
         os.environ["CVLM_PRECISION"] = args.precision
         consts = host.ovcamo_constants()
         eot_te = host.eot_for_classes(consts["names_test"].tolist())[:c.n_cls_test] if args.geometry == "demo" else spec.default_eot(c, "test")
@@ -805,6 +803,8 @@ def main():
         model.load_mapleAlphaCLIP(maple)                                                                         # demo.py:85
         model.load_state_dict(sd, strict=True)                                                                   # demo.py:88
         model.eval()
+        if args.no_overlap:
+            model.cascade().overlap_clip = False
         names = consts["names_test"].tolist()[:c.n_cls_test] if args.geometry == "demo" else [f"class{i}" for i in range(c.n_cls_test)]
         return model, names
 
@@ -904,9 +904,9 @@ def main():
     # ==================================================================================================================
     # full cascade, engine level, pipelined serving loop (the headline)
     # ==================================================================================================================
-    if args.no_overlap:
-        os.environ["CVLM_OVERLAP_CLIP"] = "0"
     cas = Cascade(sd, g, c, dev, prec)
+    if args.no_overlap:
+        cas.overlap_clip = False
     eot = host.eot_for_classes(host.ovcamo_constants()["names_test"].tolist())[:c.n_cls_test] \
         if args.geometry == "demo" else spec.default_eot(c, "test")
     bank = torch.from_numpy(host.ovcamo_constants()["bank_test"][:c.n_cls_test]).float()

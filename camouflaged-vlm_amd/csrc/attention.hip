@@ -376,10 +376,7 @@ int64_t cvlm_attention_global64_pp_workspace_bytes(const cvlm_attn_args& g);   /
 
 extern "C" int64_t cvlm_attention_workspace_bytes(const cvlm_attn_args* args) {
     if (!args) return 0;
-    static int g64 = -1, pp = -1;
-    if (g64 < 0) { const char* e = getenv("CVLM_ATTN_G64"); g64 = e ? atoi(e) : 1; }
-    if (pp < 0) { const char* e = getenv("CVLM_ATTN_G64PP"); pp = e ? atoi(e) : 1; }
-    return (g64 && pp) ? cvlm_attention_global64_pp_workspace_bytes(*args) : 0;
+    return cvlm_attention_global64_pp_workspace_bytes(*args);
 }
 
 extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
@@ -400,9 +397,7 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!g.relh_hi || !g.relw_hi || (g.split_qk == 3 && (!g.relh_lo || !g.relw_lo))) return CVLM_E_BADARG;
     if (g.grid <= 0 || g.S != g.grid * g.grid) return CVLM_E_BADARG;
     if (g.mode == 1) {
-        static int g64 = -1;
-        if (g64 < 0) { const char* e = getenv("CVLM_ATTN_G64"); g64 = e ? atoi(e) : 1; }
-        if (g64 && (g.grid == 64 || g.grid == 96)) {                           // 1024^2 / 1536^2 SAM geometries: fast paths
+        if (g.grid == 64 || g.grid == 96) {                                    // 1024^2 / 1536^2 SAM geometries: fast paths
             const int rc = cvlm_attention_global64(g, s);
             if (rc != CVLM_E_UNSUPPORTED) return rc;
         }
@@ -411,9 +406,7 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     }
     if (g.mode == 2) {
         if (g.window <= 0 || !g.pad_hi || ((g.split_qk == 3 || g.split_pv == 3) && !g.pad_lo)) return CVLM_E_BADARG;
-        static int w14 = -1;
-        if (w14 < 0) { const char* e = getenv("CVLM_ATTN_W14"); w14 = e ? atoi(e) : 1; }
-        if (w14 && g.window == 14) return cvlm_attention_window14(g, s);      // SAM window geometry fast path
+        if (g.window == 14) return cvlm_attention_window14(g, s);             // SAM window geometry fast path
         p.L = g.window; p.LTP = g.window | 1;
         p.nwx = (g.grid + g.window - 1) / g.window;
         p.S_seq = g.window * g.window;

@@ -256,9 +256,7 @@ int launch_g64(const cvlm_attn_args& g, hipStream_t s) {
 int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s);   // attention_g64pp.hip
 
 int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s) {
-    static int pp = -1;
-    if (pp < 0) { const char* e = getenv("CVLM_ATTN_G64PP"); pp = e ? atoi(e) : 1; }
-    if (g.split_qk == 3 && g.split_pv == 3 && pp) {
+    if (g.split_qk == 3 && g.split_pv == 3) {
         const int rc = cvlm_attention_global64_pp(g, s);
         if (rc != CVLM_E_UNSUPPORTED) return rc;                     // incl. CVLM_E_WORKSPACE: a missing workspace is an error, not a silent fallback
     }

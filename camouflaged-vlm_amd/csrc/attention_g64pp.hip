@@ -815,29 +815,25 @@ template <int L>
 static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int S = L * L;
     constexpr int smem = 3 * (2 * 5632) + (L == 64 ? 3 : 2) * (2 * 6144) + 256 * (L + 1) * 4;
-    static bool attr[16] = {};
-    if (cvlm_first_on_device(attr))
-        (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     const size_t plane = (size_t)g.B * g.heads * 80 * S;
     if (!g.workspace || g.workspace_bytes < cvlm_attention_global64_pp_workspace_bytes(g)) return CVLM_E_WORKSPACE;
     half_t* vt = (half_t*)g.workspace;
-    static const int pair = [] { const char* e = getenv("CVLM_ATTN_G64_PAIR"); return e ? atoi(e) : 1; }();
     hipLaunchKernelGGL(transpose_v_kernel<true>, dim3(S / 64, g.heads, g.B), dim3(256), 0, s, g, vt, vt + plane);
     CVLM_CHECK_LAUNCH();
-    if constexpr (L == 64) {
-        if (pair) {
-            constexpr int smem2 = 4 * (2 * 5632) + 4 * (2 * 6144) + 256 * (L + 1) * 4;
-            static bool attr2[16] = {};
-            if (cvlm_first_on_device(attr2))
-                (void)hipFuncSetAttribute((const void*)attn_g64pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
-            hipLaunchKernelGGL(attn_g64pair_kernel, dim3(S / 256, g.heads, g.B), dim3(512), smem2, s, g, (const half_t*)vt,
-                               (const half_t*)(vt + plane));
-            CVLM_CHECK_LAUNCH();
-            return 0;
-        }
+    if constexpr (L == 64) {                                          // 64 x 64 map: a key ROW of the map per phase (round 2)
+        constexpr int smem2 = 4 * (2 * 5632) + 4 * (2 * 6144) + 256 * (L + 1) * 4;
+        static bool attr2[16] = {};
+        if (cvlm_first_on_device(attr2))
+            (void)hipFuncSetAttribute((const void*)attn_g64pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+        hipLaunchKernelGGL(attn_g64pair_kernel, dim3(S / 256, g.heads, g.B), dim3(512), smem2, s, g, (const half_t*)vt,
+                           (const half_t*)(vt + plane));
+    } else {                                                          // 96 x 96 map: one 32-key tile per phase
+        static bool attr[16] = {};
+        if (cvlm_first_on_device(attr))
+            (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipLaunchKernelGGL(attn_g64pp_kernel<L>, dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
+                           (const half_t*)(vt + plane));
     }
-    hipLaunchKernelGGL(attn_g64pp_kernel<L>, dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
-                       (const half_t*)(vt + plane));
     CVLM_CHECK_LAUNCH();
     return 0;
 }

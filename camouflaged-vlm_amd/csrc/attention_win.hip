@@ -539,12 +539,9 @@ int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s);   // att
 
 // called from cvlm_attention() for mode 2, window 14, head_dim 80
 int cvlm_attention_window14(const cvlm_attn_args& g, hipStream_t s) {
-    // CVLM_ATTN_WIN=1: the round-2 form (two 4-wave workgroups per (window, head), every wave issues its share of the DMA);
-    // default 2: producer / consumer form, persistent over (window, head) pairs.  Re-read per call in A/B processes.
-    static int form = [] { const char* e = getenv("CVLM_ATTN_WIN"); return e ? atoi(e) : 2; }();
-    static const bool live = [] { const char* e = getenv("CVLM_GEMM_VARIANT_LIVE"); return e && atoi(e) != 0; }();
-    if (live) { const char* e = getenv("CVLM_ATTN_WIN"); form = e ? atoi(e) : 2; }
-    if (g.split_qk == 3 && g.split_pv == 3 && g.out_lo && form == 2) return cvlm_attention_window14_pc(g, s);
+    // exact mode with an h2 output: producer / consumer form, persistent over (window, head) pairs (attention_win2.hip); the kernel
+    // of this file (two 4-wave workgroups per (window, head)) serves the other precisions and a hi-plane-only output
+    if (g.split_qk == 3 && g.split_pv == 3 && g.out_lo) return cvlm_attention_window14_pc(g, s);
     if (g.split_qk == 3 && g.split_pv == 3) return launch_win<3, 3>(g, s);
     if (g.split_qk == 3 && g.split_pv == 1) return launch_win<3, 1>(g, s);
     if (g.split_qk == 1 && g.split_pv == 1) return launch_win<1, 1>(g, s);

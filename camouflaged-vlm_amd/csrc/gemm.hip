@@ -105,11 +105,10 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (p.a.out_scale == 0.f) p.a.out_scale = 1.f;
     // tuning knobs, read once per process.  A process started with CVLM_GEMM_VARIANT_LIVE=1 (tests/conftest.py,
     // tools/ab_gemm.py) re-reads them on every call so that variants can be A/B-ed and raced inside one process.
-    static int group_env = env_int("CVLM_GEMM_GROUP_M", 0), tail_env = env_int("CVLM_GEMM_TAIL", 1),
-               variant_env = env_int("CVLM_GEMM_VARIANT", 0), persist_env = env_int("CVLM_GEMM_PERSIST", 1);
+    static int tail_env = env_int("CVLM_GEMM_TAIL", 1), variant_env = env_int("CVLM_GEMM_VARIANT", 0), persist_env = env_int("CVLM_GEMM_PERSIST", 1);
     static const bool live_env = env_int("CVLM_GEMM_VARIANT_LIVE", 0) != 0;
     if (live_env) {
-        group_env = env_int("CVLM_GEMM_GROUP_M", 0); tail_env = env_int("CVLM_GEMM_TAIL", 1); variant_env = env_int("CVLM_GEMM_VARIANT", 0);
+        tail_env = env_int("CVLM_GEMM_TAIL", 1); variant_env = env_int("CVLM_GEMM_VARIANT", 0);
         persist_env = env_int("CVLM_GEMM_PERSIST", 1);
     }
     // ---- column split (one image): a grid of 256^2 tiles a little over one round -- lin1 of a ViT-H block at M = 4096 is 16 x 20 =
@@ -121,30 +120,18 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     static thread_local int in_colsplit = 0;
     static int colsplit_env = env_int("CVLM_GEMM_COLSPLIT", 1);
     if (live_env) colsplit_env = env_int("CVLM_GEMM_COLSPLIT", 1);
-    // CVLM_GEMM_COLSPLIT=2 (A/B): also for grids of several rounds whose last round is partial (proj / lin2 of a batch of 8:
-    // 128 x 5 = 640 tiles = 2.5 rounds): the columns whose tiles are whole rounds first, the rest (under one round) as the model
-    // picks; the h2-residual form included (residual planes and statistics pieces move with the column offset).
-    const bool cs_small = g.M <= 4096;
+    // (For grids of several rounds whose last round is partial -- proj / lin2 of a batch of 8 -- the same split measured slower,
+    // profiles/r03_colsplit_ab.log; that form is gone.)
     if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
-        (cs_small ? !h2res : (colsplit_env >= 2 && !il_any))) {
+        g.M <= 4096 && !h2res) {
         const int nby = (g.M + 255) / 256, nbx = (g.N + 255) / 256;
-        int c0 = 0;                                                      // column tiles of the first launch: whole rounds of tiles
-        bool ok = false;
-        if (cs_small) {
-            c0 = nby > 0 ? 256 / nby : 0;
-            const int rest_ = g.N - c0 * 256;
-            const long t1r = rest_ > 0 ? (long)((g.M + 127) / 128) * ((rest_ + 127) / 128) : 0;
-            ok = nbx > c0 && c0 * nby >= 232 && nbx * nby < 2 * 256 && rest_ >= 128 && t1r <= 256;
-        } else if ((long)nbx * nby % 256 != 0) {
-            for (int c = nbx - 1; c >= 1; --c)
-                if (((long)c * nby) % 256 == 0) { c0 = c; break; }
-            ok = c0 > 0 && (long)(nbx - c0) * nby <= 256 && (long)(nbx - c0) * nby >= 64;
-        }
+        const int c0 = nby > 0 ? 256 / nby : 0;                          // column tiles of the first launch: one round of tiles
+        const int rest_ = g.N - c0 * 256;
+        const long t1r = rest_ > 0 ? (long)((g.M + 127) / 128) * ((rest_ + 127) / 128) : 0;
+        const bool ok = nbx > c0 && c0 * nby >= 232 && nbx * nby < 2 * 256 && rest_ >= 128 && t1r <= 256;
         const int n0 = c0 * 256, rest = g.N - n0;
         if (ok && (rest & 7) == 0 && (n0 & 63) == 0) {
             cvlm_gemm_args a1 = g, a2 = g;
-            if (g.res_hi) { a2.res_hi = (const char*)g.res_hi + (int64_t)n0 * 2; a2.res_lo = (const char*)g.res_lo + (int64_t)n0 * 2; }
-            if (g.row_stats) a2.row_stats = g.row_stats + (int64_t)(n0 / 64) * g.M * 2;
             a1.N = n0;
             a2.N = rest;
             a2.w_hi = (const char*)g.w_hi + (int64_t)n0 * g.ldw * 2;
@@ -166,16 +153,13 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
 #ifdef CVLM_PROBES
     p.trace = g_trace;
 #endif
-    if (group_env < 0) group_env = 0;
     p.group_m = 8;
     p.tail_rem = 0; p.tail_split = 1; p.ws = nullptr; p.flags = nullptr;
     p.total_blocks = 0;
     const bool have_ws = g.workspace && g.workspace_bytes >= cvlm_gemm_workspace_bytes();
     hipStream_t s = (hipStream_t)stream;
-    // interleaved weight image (ABI 6): used by the big-tile kernels when the caller provides it (CVLM_GEMM_WIL=0: never)
-    static int wil_env = env_int("CVLM_GEMM_WIL", 1);
-    if (live_env) wil_env = env_int("CVLM_GEMM_WIL", 1);
-    const bool wil = wil_env && g.w_il && g.split == 3 && !conv && p.a.batch == 1 && g.ldw_il >= 2 * (int64_t)g.K && (g.ldw_il & 7) == 0;
+    // interleaved weight image (ABI 6): used by the big-tile kernels when the caller provides it
+    const bool wil = g.w_il && g.split == 3 && !conv && p.a.batch == 1 && g.ldw_il >= 2 * (int64_t)g.K && (g.ldw_il & 7) == 0;
     const bool ail = g.a_il != 0;
     if (ail && (!wil || (variant_env != 0 && variant_env != 2 && variant_env != 7))) return CVLM_E_UNSUPPORTED;
     // variant 0: auto (big tile for big problems); 1: 128x128 2-stage; 2: 256x128 3-stage; 3: 128x128 3-stage(4 waves)
@@ -240,9 +224,9 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     auto pick_ring = [&](long wgs) { return (wgs <= 256 && ring_env >= 3 && ring_env <= 5) ? ring_env : 0; };
     int small_tail_S = 0;                                             // > 0: K-parts of the 256^2 tail chain chosen here
     int small_ring = 0;                                               // > 0: slots of the deep LDS ring for a 128^2 launch of a small grid
-    static int sk_env = env_int("CVLM_GEMM_SK", 1), small_env = env_int("CVLM_GEMM_SMALL", 1);
-    if (live_env) { sk_env = env_int("CVLM_GEMM_SK", 1); small_env = env_int("CVLM_GEMM_SMALL", 1); }
-    if (g.split == 3 && !conv && p.a.batch == 1 && g.M <= 4096 && small_env != 0 && (variant_env == 0 || (variant_env == 1 && sk_env > 1))) {
+    static int sk_env = env_int("CVLM_GEMM_SK", 1);
+    if (live_env) sk_env = env_int("CVLM_GEMM_SK", 1);
+    if (g.split == 3 && !conv && p.a.batch == 1 && g.M <= 4096 && (variant_env == 0 || (variant_env == 1 && sk_env > 1))) {
         const double K = (double)g.K;
         const long t1 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
         const long t2 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
@@ -406,7 +390,6 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         // tile rows per L2 super-tile: 8 for the small tiles; the 256^2 kernel is 2-3 % faster with 4 (2 at long K),
         // i.e. ~20 (10) of an XCD's 32 co-resident tiles sharing their activation panels (tools/ab_gemm.py sweep)
         if (variant == 7) p.group_m = g.K >= 4096 ? 2 : 4;
-        if (group_env > 0) p.group_m = group_env;
         if (variant == 7 && tail_env && have_ws && p.a.batch == 1) {
             const long T = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
             const int rem = (int)(T % 256);
@@ -531,7 +514,6 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         else if (variant == 1 && small_ring_pick == 5) CVLM_LAUNCH(3, 2, 2, 15);
         else CVLM_LAUNCH(3, 2, 2, 2);
     } else {
-        if (group_env > 0) p.group_m = group_env;
         if (variant == 2) CVLM_LAUNCH(1, 4, 2, 3);
         else if (variant == 5) CVLM_LAUNCH_D(1, 2, 4, 3, 32, 0, 8);
 #ifdef CVLM_PROBES

@@ -115,7 +115,7 @@ class Linear:
         # second image with the planes interleaved per 32 k-elements (cvlm_gemm_args.w_il, ABI 6): what the big-tile kernels stage
         # the weight from; small matrices never reach those kernels, and `il=False` marks weights that only the tap / fallback
         # schedules launch (the unfused twins of LayerNorm-folded GEMMs): they stay planar and cost no second copy
-        self.w_il = hip.interleave_planes(self.w) if il and self.N * self.K >= (1 << 18) and os.environ.get("CVLM_GEMM_WIL", "1") == "1" else None
+        self.w_il = hip.interleave_planes(self.w) if il and self.N * self.K >= (1 << 18) else None
         self.bias = None
         if b is not None:
             bp = torch.zeros(self.N)
@@ -138,8 +138,8 @@ class LnLinear(Linear):
 
 def implicit_conv_ok(C: int) -> bool:
     """cvlm_gemm's implicit 3x3 convolution wants a power-of-two channel count >= 32 (include/cvlm.h, ABI 4); the tiny test
-    geometries fall back to cvlm_im2col3x3 + GEMM.  CVLM_IMPLICIT_CONV=0 forces the fallback (A/B, tests)."""
-    return C >= 32 and (C & (C - 1)) == 0 and os.environ.get("CVLM_IMPLICIT_CONV", "1") == "1"
+    geometries fall back to cvlm_im2col3x3 + GEMM."""
+    return C >= 32 and (C & (C - 1)) == 0
 
 
 class _Base:
@@ -213,7 +213,8 @@ class SamEncoder(_Base):
                                sd[P + f"blocks.{i}.mlp.lin2.bias"].detach().float().cpu() + shb, device)
                         for i in range(g.depth - 1)]
         # LayerNorm folded into the GEMMs that consume it + the residual stream kept in h2 between them: no LayerNorm
-        # kernels inside the blocks (64 launches, 4.5 ms per step at B = 8).  CVLM_LN_FOLD=0 restores the separate passes.
+        # kernels inside the blocks (64 launches, 4.5 ms per step at B = 8).  CVLM_LN_FOLD=0 (both towers) builds no folded weights
+        # and runs the separate passes; `fold_disabled` switches to them at run time (Cascade's refusal guard).
         self.ln_fold = os.environ.get("CVLM_LN_FOLD", "1") == "1"
         self.fold_disabled = False          # set by Cascade's refusal guard: rows with |mu|/sigma > 128 met -> separate LayerNorm passes
         self.blocks = []
@@ -775,8 +776,8 @@ class ClipModel(_Base):
 
         self.vblocks = [block(f"{ie}transformer.resblocks.{i}.", False) for i in range(c.vision_layers)]
         # vision tower with ln_1 / ln_2 folded into in_proj / c_fc and the residual stream in h2 (as the SAM blocks, §4):
-        # CVLM_CLIP_LN_FOLD=0 keeps the separate LayerNorm passes (the text tower, run once, always does)
-        self.ln_fold = os.environ.get("CVLM_CLIP_LN_FOLD", "1") == "1" and c.vision_width % 8 == 0
+        # CVLM_LN_FOLD=0 keeps the separate LayerNorm passes (the text tower, run once, always does)
+        self.ln_fold = os.environ.get("CVLM_LN_FOLD", "1") == "1" and c.vision_width % 8 == 0
         self.fold_disabled = False          # as SamEncoder.fold_disabled
         if self.ln_fold:
             for i, blk in enumerate(self.vblocks):
@@ -959,18 +960,17 @@ class Cascade(_Base):
                       self.dev(sd["sam_visual_proj.2.weight"]), self.dev(sd["sam_visual_proj.2.bias"]))
         self.tproj = (self.dev(sd["sam_text_proj.0.weight"]), self.dev(sd["sam_text_proj.0.bias"]),
                       Linear(sd["sam_text_proj.1.weight"], sd["sam_text_proj.1.bias"], device))
-        # CLIP pass 1 runs on a side stream under the SAM encoder (+1.3 % at B = 8, same-box A/B).  CVLM_OVERLAP_CLIP=0
-        # (bench.py --no-overlap) serialises it for profiling: co-running kernels stretch each other's durations,
+        # CLIP pass 1 runs on a side stream under the SAM encoder (+1.3 % at B = 8, same-box A/B).  `overlap_clip = False`
+        # (bench.py --no-overlap, the profiling tools) serialises it: co-running kernels stretch each other's durations,
         # which blurs per-kernel evidence.
-        self.overlap_clip = os.environ.get("CVLM_OVERLAP_CLIP", "1") == "1"
+        self.overlap_clip = True
         # pipelined loop: stage 2 of batch i and CLIP pass 1 of batch i+1 -- same weights, back to back on the side stream -- run
         # as ONE vision-tower forward over both batches (M = 9296 at B = 8: 36 row tiles instead of twice 18.2; out_proj 148
-        # tiles on 256 CUs instead of twice 76).  CVLM_FUSE_CLIP=0 keeps the two forwards apart.
-        self.fuse_clip = os.environ.get("CVLM_FUSE_CLIP", "1") == "1"
-        # Host issue order inside a step: the encoder's launches before the side stream's CLIP launches (CVLM_ENCODER_FIRST=0: the
-        # other way round, as in rounds 1-2).  It decides nothing at B = 8 (the host is far ahead of the GPU); with one image the
-        # host IS the pace of a CLIP pass and the encoder behind it started 4 ms late.
-        self.encoder_first = os.environ.get("CVLM_ENCODER_FIRST", "1") == "1"
+        # tiles on 256 CUs instead of twice 76).  `fuse_clip = False` keeps the two forwards apart (tests).
+        self.fuse_clip = True
+        # Host issue order inside a step: the encoder's first blocks BEFORE the side stream's CLIP launches (rounds 1-2 issued the
+        # CLIP pass first).  It decides nothing at B = 8 (the host is far ahead of the GPU); with one image the host IS the pace
+        # of a CLIP pass and the encoder behind it started 4 ms late (profiles/r03_encoder_first_ab.log).
         self._pending = None                                         # (masks, clip_image, pred, logits) of the batch whose stage 2 is still owed
         self._pending_stream = None
         self._clip_done = None                                       # end of the last fused CLIP forward (reader of the owned input copies)
@@ -1001,7 +1001,7 @@ class Cascade(_Base):
             import warnings
             warnings.warn(f"camouflaged_vlm_amd: {refused} token row(s) with |mean| / std > 128 were refused by the folded LayerNorm "
                           "(their images came out NaN); switching to the separate LayerNorm passes from this batch on "
-                          "(set CVLM_LN_FOLD=0 CVLM_CLIP_LN_FOLD=0 to start that way)", RuntimeWarning, stacklevel=3)
+                          "(set CVLM_LN_FOLD=0 to start that way)", RuntimeWarning, stacklevel=3)
 
     def _fold_guard_arm(self, stream) -> None:
         if not ((self.encoder.ln_fold and not self.encoder.fold_disabled) or (self.clip.ln_fold and not self.clip.fold_disabled)):
@@ -1043,28 +1043,22 @@ class Cascade(_Base):
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
             main = torch.cuda.current_stream()
-            if self.encoder_first:
-                # the host issues the ENCODER's first blocks before the CLIP pass: one image's pass is ~190 launches of a few
-                # workgroups each, the GPU runs them as fast as the host can issue them, and an encoder issued behind them started
-                # 4 ms late with the chip nearly idle until then (tools/step_timeline.py).  Five blocks (3 ms of GPU work for one
-                # image) are queued first, then the pass, then the rest: a slow host (a profiler, a loaded node) does not push the
-                # pass behind ALL of the encoder's launches either.  The side stream waits for the inputs, not for the encoder.
-                ready = torch.cuda.Event()
-                ready.record(main)
-                res = []
+            # the host issues the ENCODER's first blocks before the CLIP pass: one image's pass is ~190 launches of a few
+            # workgroups each, the GPU runs them as fast as the host can issue them, and an encoder issued behind them started
+            # 4 ms late with the chip nearly idle until then (tools/step_timeline.py).  Five blocks (3 ms of GPU work for one
+            # image) are queued first, then the pass, then the rest: a slow host (a profiler, a loaded node) does not push the
+            # pass behind ALL of the encoder's launches either.  The side stream waits for the inputs, not for the encoder.
+            ready = torch.cuda.Event()
+            ready.record(main)
+            res = []
 
-                def issue_clip():
-                    self._side.wait_event(ready)
-                    with torch.cuda.stream(self._side):
-                        res.append(self.clip.forward(clip_image, clip_mask))
-
-                feats = self.encoder.forward(inp, taps, issue_hook=issue_clip)
-                img_f, txt_f, pred, score = res[0]
-            else:
-                self._side.wait_stream(main)
+            def issue_clip():
+                self._side.wait_event(ready)
                 with torch.cuda.stream(self._side):
-                    img_f, txt_f, pred, score = self.clip.forward(clip_image, clip_mask)
-                feats = self.encoder.forward(inp, taps)
+                    res.append(self.clip.forward(clip_image, clip_mask))
+
+            feats = self.encoder.forward(inp, taps, issue_hook=issue_clip)
+            img_f, txt_f, pred, score = res[0]
             main.wait_stream(self._side)
         else:
             feats = self.encoder.forward(inp, taps)
@@ -1092,7 +1086,7 @@ class Cascade(_Base):
         pipelined=False: the current stream waits for the side stream before returning (plain stream semantics).
         pipelined=True: it does not -- the caller's next batch starts its encoder underneath this batch's decoder and
         stage 2 (a serving loop; the next `cascade()` orders itself behind the previous one, at most one batch is in flight
-        there).  CONTRACT of the pipelined loop (default form: CVLM_FUSE_CLIP=1, `_cascade_fused`): `masks` of a call are
+        there).  CONTRACT of the pipelined loop (default form: `fuse_clip`, `_cascade_fused`): `masks` of a call are
         complete after `torch.cuda.synchronize()`, but its `pred` / `logits` are OWED -- they are filled by the NEXT
         `cascade(pipelined=True)` call or by `flush()`, then complete after the following synchronize.  A caller that stops
         feeding batches MUST call `flush()`; until then `pred` holds -1 and `logits` NaN (sentinels, never stale data).
@@ -1114,27 +1108,19 @@ class Cascade(_Base):
         # run is about to overwrite (two buffers alternate)
         if self._done[self._parity] is not None:
             main.wait_event(self._done[self._parity])
-        if self.encoder_first:                                       # see infer_test
-            ready = torch.cuda.Event()
-            ready.record(main)
-            res = []
+        ready = torch.cuda.Event()                                   # encoder's first blocks, then the CLIP pass: see infer_test
+        ready.record(main)
+        res = []
 
-            def issue_clip():
-                side.wait_event(ready)
-                with torch.cuda.stream(side):
-                    res.append(self.clip.forward(clip_image, clip_mask))
-
-            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity, issue_hook=issue_clip)
-            enc_done = torch.cuda.Event()
-            enc_done.record(main)
-            img_f, txt_f, _, _ = res[0]
-        else:
-            side.wait_stream(main)
+        def issue_clip():
+            side.wait_event(ready)
             with torch.cuda.stream(side):
-                img_f, txt_f, _, _ = self.clip.forward(clip_image, clip_mask)
-            feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity)
-            enc_done = torch.cuda.Event()
-            enc_done.record(main)
+                res.append(self.clip.forward(clip_image, clip_mask))
+
+        feats = self.encoder.forward(inp, None, out_name="features%d" % self._parity, issue_hook=issue_clip)
+        enc_done = torch.cuda.Event()
+        enc_done.record(main)
+        img_f, txt_f, _, _ = res[0]
         with torch.cuda.stream(side):
             side.wait_event(enc_done)
             sparse = self.sparse_prompts(img_f, txt_f, B)
@@ -1201,7 +1187,7 @@ class Cascade(_Base):
                 self._clip_done = torch.cuda.Event()
                 self._clip_done.record(torch.cuda.current_stream())
 
-        if self.encoder_first and side is not main:                  # see infer_test
+        if side is not main:                                         # encoder's first blocks, then the CLIP pass: see infer_test
             ready = torch.cuda.Event()
             ready.record(main)
             res = []

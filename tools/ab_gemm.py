@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["CVLM_GEMM_VARIANT_LIVE"] = "1"
 from camouflaged_vlm_amd import hip
 hip.load()
-variants = [v for v in sys.argv[1:]] or ["7"]       # "7", "7:0" (variant:CVLM_GEMM_TAIL), "7:1:8" (..:CVLM_GEMM_GROUP_M) or "1:1:0:4" (..:CVLM_GEMM_SK, split-K parts) or "1:1:0:4:3:0" (..:CVLM_GEMM_RING, LDS ring slots of the small-grid 128^2 launches:CVLM_GEMM_W8, eight waves per tile:CVLM_GEMM_COLSPLIT, one round of 256^2 tiles + the remaining columns as 128^2 tiles:CVLM_GEMM_WIL, weight staged from the interleaved image)
+variants = [v for v in sys.argv[1:]] or ["7"]       # "7", "7:0" (variant:CVLM_GEMM_TAIL), "7:1:0" (third field: unused since round 4, was CVLM_GEMM_GROUP_M) or "1:1:0:4" (..:CVLM_GEMM_SK, split-K parts) or "1:1:0:4:3:0" (..:CVLM_GEMM_RING, LDS ring slots of the small-grid 128^2 launches:CVLM_GEMM_W8, eight waves per tile:CVLM_GEMM_COLSPLIT, one round of 256^2 tiles + the remaining columns as 128^2 tiles:1 / 0 = hand the interleaved weight image to the launch or not)
 shapes = [("sam qkv", 32768, 3840, 1280), ("sam proj", 32768, 1280, 1280), ("sam lin1", 32768, 5120, 1280), ("sam lin2", 32768, 1280, 5120)]
 if os.environ.get("SHAPES") == "win":          # window blocks: 8 images x 25 windows x 196 tokens
     shapes = [("win qkv", 39200, 3840, 1280), ("win proj", 39200, 1280, 1280), ("win lin1", 39200, 5120, 1280), ("win lin2", 39200, 1280, 5120)]
@@ -39,17 +39,16 @@ for name, M, N, K in shapes:
             os.environ["CVLM_GEMM_VARIANT"] = v.split(":")[0]
             f = v.split(":")
             os.environ["CVLM_GEMM_TAIL"] = f[1] if len(f) > 1 else "1"
-            os.environ["CVLM_GEMM_GROUP_M"] = f[2] if len(f) > 2 else "0"
             os.environ["CVLM_GEMM_SK"] = f[3] if len(f) > 3 else "1"
             os.environ["CVLM_GEMM_RING"] = f[4] if len(f) > 4 else "4"
             os.environ["CVLM_GEMM_W8"] = f[5] if len(f) > 5 else "1"
             os.environ["CVLM_GEMM_COLSPLIT"] = f[6] if len(f) > 6 else "1"
-            os.environ["CVLM_GEMM_WIL"] = f[7] if len(f) > 7 else "1"
-            hip.gemm(a, nextw(), M, N, K, out_h2=out, split=3, workspace=ws, w_il=curwil())
+            use_il = (f[7] if len(f) > 7 else "1") != "0"
+            hip.gemm(a, nextw(), M, N, K, out_h2=out, split=3, workspace=ws, w_il=curwil() if use_il else None)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                hip.gemm(a, nextw(), M, N, K, out_h2=out, split=3, workspace=ws, w_il=curwil())
+                hip.gemm(a, nextw(), M, N, K, out_h2=out, split=3, workspace=ws, w_il=curwil() if use_il else None)
             e1.record(); torch.cuda.synchronize()
             res[v].append(e0.elapsed_time(e1) * 100)
     print(f"sam {name:9s} " + "  ".join(f"v{v}: {min(r):7.1f} us" for v, r in res.items()), flush=True)

@@ -1,6 +1,6 @@
 set -x
 # L2 (TCC) request counters of the big GEMM shapes with the operands staged from planes vs from the 128-byte-row images
-# (weights: CVLM_GEMM_WIL; the probe passes the weight image only -- activations of tools/ab_gemm.py are planar).
+# (weights: eighth field of the tools/ab_gemm.py variant string, 1 / 0 = with / without the weight image; the probe passes the weight image only -- activations of tools/ab_gemm.py are planar).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_l2
 rm -rf $O; mkdir -p $O

@@ -4,7 +4,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_l2c
 rm -rf $O; mkdir -p $O
 for MODE in planes images; do
-  if [ $MODE = planes ]; then export CVLM_GEMM_WIL=0 CVLM_GEMM_AIL=0; else export CVLM_GEMM_WIL=1 CVLM_GEMM_AIL=1; fi
+  # round 3 also switched the WEIGHT images off here (CVLM_GEMM_WIL=0; result: profiles/r03_l2_requests.log); that switch is gone
+  # since round 4 (the images are always used), so "planes" now means planar ACTIVATIONS only
+  if [ $MODE = planes ]; then export CVLM_GEMM_AIL=0; else export CVLM_GEMM_AIL=1; fi
   rocprofv3 --pmc TCC_REQ_sum TCC_READ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/$MODE -- python3 bench.py --steps 2 --warmup 1 --no-overlap --no-cpu-baseline --no-roofline --no-power > $O/run_$MODE.log 2>&1
 done
 python - <<'PY'

@@ -2,7 +2,8 @@
   make -C camouflaged-vlm_amd/csrc EXTRA=-DCVLM_PROBES LIBDIR=../lib_probe
   CVLM_PROBE_LIB=camouflaged-vlm_amd/lib_probe/libcvlm_hip.so python tools/trace_attn_win.py"""
 import ctypes as C, os, sys
-os.environ["CVLM_ATTN_WIN"] = "1"      # the timeline stamps live in the round-2 form of the kernel (attention_win.hip)
+# the timeline stamps live in the two-workgroups-per-pair kernel (attention_win.hip), which since round 4 runs for every precision
+# but exact-with-h2-output (that one is the producer / consumer form, attention_win2.hip): the trace below uses split_pv = 1
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from camouflaged_vlm_amd import hip
@@ -13,7 +14,7 @@ qkv = hip.H2(torch.randn(2, B * S, 3 * D, device="cuda").half())
 out = hip.H2.empty(B * S, D)
 rw = hip.H2((torch.randn(2, 27, hd, device="cuda") * 0.1).half())
 pad = hip.H2((torch.randn(2, 3 * D, device="cuda") * 0.1).half())
-fn = lambda: hip.attention(qkv, out, B, S, H, hd, mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw, split_qk=3, split_pv=3, head_major=True)
+fn = lambda: hip.attention(qkv, out, B, S, H, hd, mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw, split_qk=3, split_pv=1, head_major=True)
 nwg = 2 * H * B * 25
 buf = torch.zeros(2 * nwg * 8, dtype=torch.int64, device="cuda")
 for _ in range(2): fn()
