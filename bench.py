@@ -264,6 +264,24 @@ def physical_cores() -> int:
     return len(seen) or len(allowed)
 
 
+def cgroup_cpu_limit():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else round(float(q) / float(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -1016,7 +1034,11 @@ def main():
                     ta.append(time.perf_counter() - tc)
             all_cores = {"value": round(1.0 / ta[1], 5), "unit": "images/s", "cores": torch.get_num_threads(),
                          "sample": f"1 warm-up ({ta[0]:.2f} s) + 1 image ({ta[1]:.2f} s) of the same oracle cascade with "
-                                   f"torch.set_num_threads({phys}) = every physical core this process may use"}
+                                   f"torch.set_num_threads({phys}) = every physical core this process may use",
+                         "cgroup_cpu_limit": cgroup_cpu_limit(),
+                         "note": "SURVEY.md section 8(d) protocol (all physical host cores).  Where the container's CPU quota "
+                                 "(cgroup_cpu_limit, in CPUs) is far below the core count, the extra threads only contend for the "
+                                 "same quota and this figure comes out BELOW the 16-thread one: `value` is then the best the host allows"}
             torch.set_num_threads(cores)
         cpu = {"value": round(1.0 / s_img, 5), "unit": "images/s", "cores": cores, "kind": "port",
                "all_physical_cores": all_cores,

@@ -462,117 +462,157 @@ __global__ __launch_bounds__(64) void normalize_add_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// small fp32 attention (two-way decoder).  hd <= 32.
+// small fp32 attention (two-way decoder).  hd = 16 or 32.
 // ------------------------------------------------------------------------------------------------
-constexpr int SA_MAXHD = 32;
 
-// few keys: one thread per (b, q, h)
+// Output of a small-attention row piece: f32 and / or h2 planes (the out_proj GEMM's operand: no cvlm_split_f32 launch in between)
+template <int HD>
+__device__ __forceinline__ void sa_store(const float (&o)[HD], float* __restrict__ of, half_t* __restrict__ oh, half_t* __restrict__ ol) {
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+        if (of) *(float4*)(of + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
+        if (oh) {
+            half_t h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_h2(o[d + j], h[j], l[j]);
+            *(half4*)(oh + d) = half4{h[0], h[1], h[2], h[3]};
+            *(half4*)(ol + d) = half4{l[0], l[1], l[2], l[3]};
+        }
+    }
+}
+
+// few keys: one thread per (b, q, h); HD = 16 / 32 (the decoder's head dims), 16-byte loads and stores
+template <int HD>
 __global__ __launch_bounds__(256) void small_attn_thread_kernel(const float* __restrict__ q, int64_t ldq,
                                                                 const float* __restrict__ k, int64_t ldk,
                                                                 const float* __restrict__ v, int64_t ldv,
-                                                                float* __restrict__ out, int64_t ldo, int nq, int nk,
-                                                                int heads, int hd, int64_t total) {
-    const float sc = 1.0f / sqrtf((float)hd);
+                                                                float* __restrict__ out, int64_t ldo, half_t* __restrict__ out_hi,
+                                                                half_t* __restrict__ out_lo, int64_t ldoh, int nq, int nk,
+                                                                int heads, int64_t total) {
+    const float sc = 1.0f / sqrtf((float)HD);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int h = (int)(i % heads);
         const int qi = (int)((i / heads) % nq);
         const int64_t b = i / ((int64_t)heads * nq);
-        const float* qp = q + (b * nq + qi) * ldq + h * hd;
-        float qr[SA_MAXHD], acc[SA_MAXHD];
+        const float* qp = q + (b * nq + qi) * ldq + h * HD;
+        float qr[HD], acc[HD];
 #pragma unroll
-        for (int d = 0; d < SA_MAXHD; ++d) { qr[d] = d < hd ? qp[d] : 0.f; acc[d] = 0.f; }
+        for (int d = 0; d < HD; d += 4) {
+            const float4 a = *(const float4*)(qp + d);
+            qr[d] = a.x; qr[d + 1] = a.y; qr[d + 2] = a.z; qr[d + 3] = a.w;
+            acc[d] = acc[d + 1] = acc[d + 2] = acc[d + 3] = 0.f;
+        }
         float mx = -INFINITY, l = 0.f;
         for (int j = 0; j < nk; ++j) {
-            const float* kp = k + (b * nk + j) * ldk + h * hd;
-            const float* vp = v + (b * nk + j) * ldv + h * hd;
-            float s = 0.f;
+            const float* kp = k + (b * nk + j) * ldk + h * HD;
+            const float* vp = v + (b * nk + j) * ldv + h * HD;
+            float s = 0.f, vr[HD];
 #pragma unroll
-            for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) s += qr[d] * kp[d];
+            for (int d = 0; d < HD; d += 4) {
+                const float4 a = *(const float4*)(kp + d), c = *(const float4*)(vp + d);
+                s += qr[d] * a.x; s += qr[d + 1] * a.y; s += qr[d + 2] * a.z; s += qr[d + 3] * a.w;
+                vr[d] = c.x; vr[d + 1] = c.y; vr[d + 2] = c.z; vr[d + 3] = c.w;
+            }
             s *= sc;
             const float mn = fmaxf(mx, s);
             const float f = expf(mx - mn), pj = expf(s - mn);
             l = l * f + pj;
 #pragma unroll
-            for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) acc[d] = acc[d] * f + pj * vp[d];
+            for (int d = 0; d < HD; ++d) acc[d] = acc[d] * f + pj * vr[d];
             mx = mn;
         }
-        float* op = out + (b * nq + qi) * ldo + h * hd;
 #pragma unroll
-        for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) op[d] = acc[d] / l;
+        for (int d = 0; d < HD; ++d) acc[d] = acc[d] / l;
+        const int64_t row = b * nq + qi;
+        sa_store<HD>(acc, out ? out + row * ldo + h * HD : nullptr, out_hi ? out_hi + row * ldoh + h * HD : nullptr,
+                     out_lo ? out_lo + row * ldoh + h * HD : nullptr);
     }
 }
 
-// many keys: one workgroup (4 waves) per (b, q, h); threads stride over keys with 16-byte loads, partial softmax states
-// are merged through LDS.  (One wave per (b, q, h) with scalar loads used 96 CUs and took 310 us on the 6 x 4096 decoder
-// attentions.)
+// many keys: one workgroup (4 waves) per (b, q, h); threads stride over keys, FOUR keys' rows requested before the first is used
+// (one key per trip made every trip wait a full load latency: 28 us for 16 trips), partial softmax states are merged through LDS.
+template <int HD>
 __global__ __launch_bounds__(256) void small_attn_wave_kernel(const float* __restrict__ q, int64_t ldq,
                                                               const float* __restrict__ k, int64_t ldk,
                                                               const float* __restrict__ v, int64_t ldv,
-                                                              float* __restrict__ out, int64_t ldo, int nq, int nk,
-                                                              int heads, int hd, int64_t total) {
-    const float sc = 1.0f / sqrtf((float)hd);
+                                                              float* __restrict__ out, int64_t ldo, half_t* __restrict__ out_hi,
+                                                              half_t* __restrict__ out_lo, int64_t ldoh, int nq, int nk, int heads) {
+    constexpr int U = 4;
+    const float sc = 1.0f / sqrtf((float)HD);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = blockIdx.x;
     const int h = (int)(i % heads);
     const int qi = (int)((i / heads) % nq);
     const int64_t b = i / ((int64_t)heads * nq);
-    const float* qp = q + (b * nq + qi) * ldq + h * hd;
-    float qr[SA_MAXHD], acc[SA_MAXHD];
+    const float* qp = q + (b * nq + qi) * ldq + h * HD;
+    float qr[HD], acc[HD];
 #pragma unroll
-    for (int d = 0; d < SA_MAXHD; ++d) { qr[d] = d < hd ? qp[d] : 0.f; acc[d] = 0.f; }
+    for (int d = 0; d < HD; d += 4) {
+        const float4 a = *(const float4*)(qp + d);
+        qr[d] = a.x; qr[d + 1] = a.y; qr[d + 2] = a.z; qr[d + 3] = a.w;
+        acc[d] = acc[d + 1] = acc[d + 2] = acc[d + 3] = 0.f;
+    }
     float mx = -INFINITY, l = 0.f;
-    const bool vec = ((hd & 3) == 0) && ((ldk & 3) == 0) && ((ldv & 3) == 0) && ((((uintptr_t)k | (uintptr_t)v) & 15) == 0);
-    for (int j = threadIdx.x; j < nk; j += 256) {
-        const float* kp = k + (b * nk + j) * ldk + h * hd;
-        const float* vp = v + (b * nk + j) * ldv + h * hd;
-        float kr[SA_MAXHD], vr[SA_MAXHD];
-        if (vec) {
+    for (int j0 = threadIdx.x; j0 < nk; j0 += 256 * U) {
+        float4 kr[U][HD / 4], vr[U][HD / 4];
 #pragma unroll
-            for (int d = 0; d < SA_MAXHD; d += 4)
-                if (d < hd) {
-                    const float4 a = *(const float4*)(kp + d), c = *(const float4*)(vp + d);
-                    kr[d] = a.x; kr[d + 1] = a.y; kr[d + 2] = a.z; kr[d + 3] = a.w;
-                    vr[d] = c.x; vr[d + 1] = c.y; vr[d + 2] = c.z; vr[d + 3] = c.w;
-                }
-        } else {
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + 256 * u;
+            const int jc = j < nk ? j : nk - 1;
+            const float* kp = k + (b * nk + jc) * ldk + h * HD;
+            const float* vp = v + (b * nk + jc) * ldv + h * HD;
 #pragma unroll
-            for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) { kr[d] = kp[d]; vr[d] = vp[d]; }
+            for (int d = 0; d < HD / 4; ++d) { kr[u][d] = *(const float4*)(kp + 4 * d); vr[u][d] = *(const float4*)(vp + 4 * d); }
         }
-        float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) s += qr[d] * kr[d];
-        s *= sc;
-        const float mn = fmaxf(mx, s);
-        const float f = expf(mx - mn), pj = expf(s - mn);
-        l = l * f + pj;
+        for (int u = 0; u < U; ++u) {
+            if (j0 + 256 * u >= nk) break;
+            float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < SA_MAXHD; ++d) if (d < hd) acc[d] = acc[d] * f + pj * vr[d];
-        mx = mn;
+            for (int d = 0; d < HD / 4; ++d)
+                s += qr[4 * d] * kr[u][d].x + qr[4 * d + 1] * kr[u][d].y + qr[4 * d + 2] * kr[u][d].z + qr[4 * d + 3] * kr[u][d].w;
+            s *= sc;
+            const float mn = fmaxf(mx, s);
+            const float f = expf(mx - mn), pj = expf(s - mn);
+            l = l * f + pj;
+#pragma unroll
+            for (int d = 0; d < HD / 4; ++d) {
+                acc[4 * d] = acc[4 * d] * f + pj * vr[u][d].x;         acc[4 * d + 1] = acc[4 * d + 1] * f + pj * vr[u][d].y;
+                acc[4 * d + 2] = acc[4 * d + 2] * f + pj * vr[u][d].z; acc[4 * d + 3] = acc[4 * d + 3] * f + pj * vr[u][d].w;
+            }
+            mx = mn;
+        }
     }
     // wave-level merge, then the four waves through LDS
-    __shared__ float red[4][SA_MAXHD + 2];
+    __shared__ float red[4][HD + 2];
     const float M = wave_max(mx);
     const float f = (mx == -INFINITY) ? 0.f : expf(mx - M);
     l = wave_sum(l * f);
 #pragma unroll
-    for (int d = 0; d < SA_MAXHD; ++d) {
-        if (d < hd) {
-            const float a = wave_sum(acc[d] * f);
-            if (lane == 0) red[wave][d] = a;
-        }
+    for (int d = 0; d < HD; ++d) {
+        const float a = wave_sum(acc[d] * f);
+        if (lane == 0) red[wave][d] = a;
     }
-    if (lane == 0) { red[wave][SA_MAXHD] = M; red[wave][SA_MAXHD + 1] = l; }
+    if (lane == 0) { red[wave][HD] = M; red[wave][HD + 1] = l; }
     __syncthreads();
-    if (threadIdx.x < hd) {
-        const float Mb = fmaxf(fmaxf(red[0][SA_MAXHD], red[1][SA_MAXHD]), fmaxf(red[2][SA_MAXHD], red[3][SA_MAXHD]));
+    if (threadIdx.x < HD) {
+        const float Mb = fmaxf(fmaxf(red[0][HD], red[1][HD]), fmaxf(red[2][HD], red[3][HD]));
         float num = 0.f, den = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float fw = (red[w][SA_MAXHD] == -INFINITY) ? 0.f : expf(red[w][SA_MAXHD] - Mb);
+            const float fw = (red[w][HD] == -INFINITY) ? 0.f : expf(red[w][HD] - Mb);
             num += red[w][threadIdx.x] * fw;
-            den += red[w][SA_MAXHD + 1] * fw;
+            den += red[w][HD + 1] * fw;
         }
-        out[(b * nq + qi) * ldo + h * hd + threadIdx.x] = num / den;
+        const float o = num / den;
+        const int64_t row = b * nq + qi;
+        if (out) out[row * ldo + h * HD + threadIdx.x] = o;
+        if (out_hi) {
+            half_t hh, ll;
+            split_h2(o, hh, ll);
+            out_hi[row * ldoh + h * HD + threadIdx.x] = hh;
+            out_lo[row * ldoh + h * HD + threadIdx.x] = ll;
+        }
     }
 }
 
@@ -750,20 +790,34 @@ int cvlm_normalize_add(const float* x, const float* add, int32_t R, int32_t D, f
     return 0;
 }
 
-int cvlm_small_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
-                         float* out, int64_t ldo, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
-                         void* stream) {
-    if (!q || !k || !v || !out || hd <= 0 || hd > SA_MAXHD || nk <= 0 || nq <= 0) return CVLM_E_BADARG;
+int cvlm_small_attention_h2(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out, int64_t ldo,
+                            void* out_hi, void* out_lo, int64_t ldoh, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
+                            void* stream) {
+    if (!q || !k || !v || (!out && !out_hi) || (out_hi && !out_lo) || nk <= 0 || nq <= 0 || B <= 0 || heads <= 0) return CVLM_E_BADARG;
+    if (hd != 16 && hd != 32) return CVLM_E_UNSUPPORTED;             // the decoder's head dims (internal 128 / 256 over 8 heads)
+    // 16-byte accesses: every row pitch and base a multiple of four floats (four halves for the planes)
+    if (((ldq | ldk | ldv | ldo | ldoh) & 3) || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) ||
+        (((uintptr_t)out_hi | (uintptr_t)out_lo) & 7))
+        return CVLM_E_BADARG;
     const int64_t total = (int64_t)B * nq * heads;
+    hipStream_t s = (hipStream_t)stream;
+    half_t* oh = (half_t*)out_hi;
+    half_t* ol = (half_t*)out_lo;
     if (nk <= 64) {
-        hipLaunchKernelGGL(small_attn_thread_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, q, ldq,
-                           k, ldk, v, ldv, out, ldo, nq, nk, heads, hd, total);
+        if (hd == 16) hipLaunchKernelGGL(small_attn_thread_kernel<16>, dim3(grid_for(total)), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, out, ldo, oh, ol, ldoh, nq, nk, heads, total);
+        else hipLaunchKernelGGL(small_attn_thread_kernel<32>, dim3(grid_for(total)), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, out, ldo, oh, ol, ldoh, nq, nk, heads, total);
     } else {
-        hipLaunchKernelGGL(small_attn_wave_kernel, dim3((unsigned)total), dim3(256), 0,
-                           (hipStream_t)stream, q, ldq, k, ldk, v, ldv, out, ldo, nq, nk, heads, hd, total);
+        if (hd == 16) hipLaunchKernelGGL(small_attn_wave_kernel<16>, dim3((unsigned)total), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, out, ldo, oh, ol, ldoh, nq, nk, heads);
+        else hipLaunchKernelGGL(small_attn_wave_kernel<32>, dim3((unsigned)total), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, out, ldo, oh, ol, ldoh, nq, nk, heads);
     }
     CVLM_CHECK_LAUNCH();
     return 0;
+}
+
+int cvlm_small_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                         float* out, int64_t ldo, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
+                         void* stream) {
+    return cvlm_small_attention_h2(q, ldq, k, ldk, v, ldv, out, ldo, nullptr, nullptr, 0, B, nq, nk, heads, hd, stream);
 }
 
 int cvlm_abi_version(void) { return CVLM_ABI_VERSION; }

@@ -472,6 +472,7 @@ class MaskDecoder(_Base):
         self.up = {n: (convT2(n + ".0"), convT2(n + ".3")) for n in ("output_upscaling", "embedding_encoder")}
         self.mf = (convT3("embedding_maskfeature.0"), convT3("embedding_maskfeature.3"))
         self.pe: Optional[torch.Tensor] = None
+        self._merged(sd, P)
 
     def _upscale(self, x_h2: H2, B: int, G: int, name: str, final_gelu: bool, out: torch.Tensor,
                  out_h2: Optional[H2] = None) -> torch.Tensor:
@@ -488,104 +489,184 @@ class MaskDecoder(_Base):
                   act=ACT_GELU if final_gelu else ACT_NONE, **kw)
         return out
 
-    def _attn(self, name: str, q: H2, k: H2, v: H2, B: int, nq: int, nk: int, out: torch.Tensor) -> None:
-        """transformer_maskdecoder_edge.py:250-272."""
-        ws, heads = self.ws, self.g.dec_heads
-        I = self.lin[name + ".q_proj"].N
-        qp, kp, vp = ws.f32("a_q", B * nq, I), ws.f32("a_k", B * nk, I), ws.f32("a_v", B * nk, I)
-        self.gemm(q, self.lin[name + ".q_proj"], B * nq, out_f32=qp)
-        self.gemm(k, self.lin[name + ".k_proj"], B * nk, out_f32=kp)
-        self.gemm(v, self.lin[name + ".v_proj"], B * nk, out_f32=vp)
-        o = ws.f32("a_o", B * nq, I)
-        hip.small_attention(qp, kp, vp, o, B, nq, nk, heads, I // heads)
-        oh = ws.h2("a_oh", B * nq, I)
-        hip.split_f32(o, oh)
-        self.gemm(oh, self.lin[name + ".out_proj"], B * nq, out_f32=out)
+    # ---- merged projections and image-independent terms (round 4: 133 -> ~75 launches per forward) ---------------------------------
+    # Every attention of the two-way transformer projects `x + pe` for q / k and `x` for v (transformer_maskdecoder_edge.py:174-212):
+    #   (x + pe) W^T + b = x W^T + b + (pe W^T),
+    # and pe (the dense positional encoding for image rows, the token embeddings for token rows) does not depend on the image: the
+    # products pe W^T are constants of the model, added to the GEMM as its f32 residual.  So the projections read the stream itself
+    # (the h2 planes its LayerNorm writes beside the f32 rows: no add / split launches), q | k | v that share an input run as ONE GEMM
+    # over the concatenated weights, the four condition attentions' k / v projections (inputs 2 cond and cond, :98-99) as two GEMMs
+    # for both layers, the attention writes h2 planes for out_proj, out_proj adds the stream as its residual, and layer 0's self
+    # attention (tokens only, :174-176) is computed once.
+    def _merged(self, sd, P: str) -> None:
+        g = self.g
+        W = lambda n: sd[P + n + ".weight"].detach().float().cpu()
+        Bv = lambda n: sd[P + n + ".bias"].detach().float().cpu()
+        cat = lambda names: Linear(torch.cat([W(n) for n in names], 0), torch.cat([Bv(n) for n in names], 0), self.device)
+        self.m: Dict[str, Linear] = {}
+        cond_names = []
+        for i in range(g.dec_depth):
+            L = f"transformer.layers.{i}."
+            self.m[L + "self_qkv"] = cat([L + "self_attn." + x for x in ("q_proj", "k_proj", "v_proj")])
+            self.m[L + "t2i_kv"] = cat([L + "cross_attn_token_to_image." + x for x in ("k_proj", "v_proj")])
+            self.m[L + "i2t_kv"] = cat([L + "cross_attn_image_to_token." + x for x in ("k_proj", "v_proj")])
+            cond_names += [L + "cross_attn_token_to_cond", L + "cross_attn_image_to_cond"]
+        self.m["fin_kv"] = cat(["transformer.final_attn_token_to_image." + x for x in ("k_proj", "v_proj")])
+        self.m["cond_k"] = cat([n + ".k_proj" for n in cond_names])
+        self.m["cond_v"] = cat([n + ".v_proj" for n in cond_names])
+        self.cond_slot = {n: j for j, n in enumerate(cond_names)}
+        self.consts: Optional[Dict[str, object]] = None
+
+    def _build_consts(self, gauss: torch.Tensor) -> None:
+        """pe W^T for every projection that the reference feeds `x + pe`, and layer 0's queries (image independent)."""
+        g, dev = self.g, self.device
+        G, C, T, NT = g.grid, g.prompt_embed_dim, g.grid * g.grid, self.tokens.shape[0]
+        self.pe = torch.empty(T, C, device=dev)
+        hip.dense_pe(gauss, G, C, self.pe)
+        peh, tokh = H2.empty(T, C, device=dev), H2.empty(NT, C, device=dev)
+        hip.split_f32(self.pe, peh)
+        hip.split_f32(self.tokens, tokh)
+        c: Dict[str, object] = {}
+
+        def proj(a_h2, rows, name, width, col0=0, out=None):          # out[:, col0:col0 + N] = a . W^T (no bias); other columns stay 0
+            lin = self.lin[name]
+            out = torch.zeros(rows, width, device=dev) if out is None else out
+            self.gemm(a_h2, lin, rows, out_f32=out[:, col0:], ldo=width, bias=None)
+            return out
+        for i in range(g.dec_depth):
+            L = f"transformer.layers.{i}."
+            I = self.lin[L + "cross_attn_token_to_image.q_proj"].N
+            c[L + "t2i_q"] = proj(tokh, NT, L + "cross_attn_token_to_image.q_proj", I)
+            c[L + "t2i_kv"] = proj(peh, T, L + "cross_attn_token_to_image.k_proj", 2 * I)
+            c[L + "t2c_q"] = proj(tokh, NT, L + "cross_attn_token_to_cond.q_proj", I)
+            c[L + "i2c_q"] = proj(peh, T, L + "cross_attn_image_to_cond.q_proj", I)
+            c[L + "i2t_q"] = proj(peh, T, L + "cross_attn_image_to_token.q_proj", I)
+            c[L + "i2t_kv"] = proj(tokh, NT, L + "cross_attn_image_to_token.k_proj", 2 * I)
+            if i > 0:
+                sq = proj(tokh, NT, L + "self_attn.q_proj", 3 * C)
+                c[L + "self_qkv"] = proj(tokh, NT, L + "self_attn.k_proj", 3 * C, col0=C, out=sq)
+        I = self.lin["transformer.final_attn_token_to_image.q_proj"].N
+        c["fin_q"] = proj(tokh, NT, "transformer.final_attn_token_to_image.q_proj", I)
+        c["fin_kv"] = proj(peh, T, "transformer.final_attn_token_to_image.k_proj", 2 * I)
+        # layer 0: queries = LN(self_attn(tokens, tokens, tokens)) -- "replaces instead of adds" (:174-176)
+        L = "transformer.layers.0."
+        qkv = torch.empty(NT, 3 * C, device=dev)
+        self.gemm(tokh, self.m[L + "self_qkv"], NT, out_f32=qkv)
+        oh = H2.empty(NT, C, device=dev)
+        hip.small_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, 1, NT, NT, g.dec_heads, C // g.dec_heads, out_h2=oh)
+        ao = torch.empty(NT, C, device=dev)
+        self.gemm(oh, self.lin[L + "self_attn.out_proj"], NT, out_f32=ao)
+        q0 = torch.empty(NT, C, device=dev)
+        hip.layernorm(ao, *self.ln[L + "norm1"], 1e-5, NT, C, out_f32=q0)
+        c["q0"] = q0
+        self.consts = c
+
+    def _bgemm(self, a: H2, lin: Linear, B: int, rows: int, out: torch.Tensor, const: torch.Tensor, **kw) -> None:
+        """out[b] = a[b] . W^T + bias + const for B images of `rows` rows each; const f32 [rows][N] is shared by the images
+        (one problem per image with residual stride 0 when B > 1)."""
+        if B == 1:
+            self.gemm(a, lin, rows, out_f32=out, residual=const, **kw)
+        else:
+            self.gemm(a, lin, rows, out_f32=out, residual=const, batch=B, stride_a=rows * lin.K, stride_r=0, stride_o=rows * lin.N, **kw)
 
     def forward(self, feats: torch.Tensor, sparse: torch.Tensor, no_mask: torch.Tensor, gauss: torch.Tensor,
                 B: int, taps: Optional[dict] = None) -> torch.Tensor:
-        """feats f32 [B*T][C]; sparse f32 [B][2][C] -> low-res mask logits f32 [B][4G][4G] (mask 0, :133-135)."""
+        """feats f32 [B*T][C]; sparse f32 [B][2][C] -> low-res mask logits f32 [B][4G][4G] (mask 0, :133-135).
+        mask_decoder_edge.py:96-190, transformer_maskdecoder_edge.py:62-214."""
         g, ws = self.g, self.ws
-        G, C, T = g.grid, g.prompt_embed_dim, g.grid * g.grid
-        if self.pe is None:
-            self.pe = torch.empty(T, C, device=self.device)
-            hip.dense_pe(gauss, G, C, self.pe)
+        G, C, T, H = g.grid, g.prompt_embed_dim, g.grid * g.grid, g.dec_heads
+        NT = self.tokens.shape[0]
+        if self.consts is None:
+            self._build_consts(gauss)
+        cst = self.consts
         fh = ws.h2("feats_h", B * T, C)
         hip.split_f32(feats, fh)
         edge_feat = self._upscale(fh, B, G, "embedding_encoder", False, ws.f32("edge_feat", B * 16 * T, C // 8))
-        # :150-158 tokens / src
-        NT = 6
-        queries = ws.f32("queries", B * NT, C)
-        queries.view(B, NT, C).copy_(self.tokens)
-        keys = ws.f32("keys", B * T, C)
-        hip.add_rows(feats, no_mask, 1, B * T, C, out_f32=keys)
-        cond_v = ws.h2("cond_v", B * 2, C)
-        cond_k = ws.h2("cond_k", B * 2, C)
-        hip.split_f32(sparse, cond_v)
-        hip.add_rows(sparse, None, 1, B * 2, C, scale=2.0, out_h2=cond_k)            # cond + cond_pe (:98-99)
-        qh, kh, vh = ws.h2("d_q", B * NT, C), ws.h2("d_k", B * T, C), ws.h2("d_v", B * T, C)
-        tq, tk = ws.h2("d_tq", B * NT, C), ws.h2("d_tk", B * NT, C)
+        # :150-158 tokens / src; every stream lives as f32 rows + the h2 planes of the same values
+        keys, keys_h = ws.f32("keys", B * T, C), ws.h2("d_keys_h", B * T, C)
+        hip.add_rows(feats, no_mask, 1, B * T, C, out_f32=keys, out_h2=keys_h)
+        queries, queries_h = ws.f32("queries", B * NT, C), ws.h2("d_queries_h", B * NT, C)
+        zeros = ws._get("f32", "d_zeros", B * NT * C, torch.float32, True).view(B * NT, C)    # zero-filled once, never written
+        hip.add_rows(zeros, cst["q0"], NT, B * NT, C, out_f32=queries, out_h2=queries_h)        # layer 0's queries for every image
+        # condition tokens: k = (cond + cond_pe) W_k = 2 cond W_k (:98-99), v = cond W_v, for the four condition attentions at once
+        cond_h = ws.h2("cond_h", B * 2, C)
+        hip.split_f32(sparse, cond_h)
+        NC = self.m["cond_k"].N
+        ck, cv = ws.f32("cond_kp", B * 2, NC), ws.f32("cond_vp", B * 2, NC)
+        self.gemm(cond_h, self.m["cond_k"], B * 2, out_f32=ck, alpha=2.0)
+        self.gemm(cond_h, self.m["cond_v"], B * 2, out_f32=cv)
         ao_q, ao_k = ws.f32("ao_q", B * NT, C), ws.f32("ao_k", B * T, C)
         hidh = ws.h2("d_hid", B * NT, g.dec_mlp)
-        mo = ws.f32("d_mlp", B * NT, C)
+
+        def token_attn(name: str, qp, k, v, nk: int, norm) -> None:
+            """softmax(q k^T) v -> out_proj + queries -> LayerNorm -> queries (f32 + h2); q / k / v already projected"""
+            I = self.lin[name + ".out_proj"].K
+            oh = ws.h2("t_o%d" % I, B * NT, I)
+            hip.small_attention(qp, k, v, None, B, NT, nk, H, I // H, out_h2=oh)
+            self.gemm(oh, self.lin[name + ".out_proj"], B * NT, residual=queries, out_f32=ao_q)
+            hip.layernorm(ao_q, *norm, 1e-5, B * NT, C, out_f32=queries, out_h2=queries_h)
+
+        def image_attn(name: str, qconst, k, v, nk: int, norm) -> None:
+            I = self.lin[name + ".out_proj"].K
+            iq, ioh = ws.f32("i_q", B * T, I), ws.h2("i_o", B * T, I)
+            self._bgemm(keys_h, self.lin[name + ".q_proj"], B, T, iq, qconst)
+            hip.small_attention(iq, k, v, None, B, T, nk, H, I // H, out_h2=ioh)
+            self.gemm(ioh, self.lin[name + ".out_proj"], B * T, residual=keys, out_f32=ao_k)
+            hip.layernorm(ao_k, *norm, 1e-5, B * T, C, out_f32=keys, out_h2=keys_h)
+
+        def tokens_to_image(name: str, qconst, kvlin: Linear, kvconst, norm) -> None:
+            I = self.lin[name + ".q_proj"].N
+            qp, kv = ws.f32("t_q", B * NT, I), ws.f32("i_kv", B * T, 2 * I)
+            self._bgemm(queries_h, self.lin[name + ".q_proj"], B, NT, qp, qconst)
+            self._bgemm(keys_h, kvlin, B, T, kv, kvconst)
+            token_attn(name, qp, kv[:, :I], kv[:, I:], T, norm)
+
         for i in range(g.dec_depth):
             L = f"transformer.layers.{i}."
             ln = lambda n: self.ln[L + n]
-            # self attention (:174-180); layer 0 replaces the queries
-            if i == 0:
-                hip.split_f32(queries, tq)
-                self._attn(L + "self_attn", tq, tq, tq, B, NT, NT, ao_q)
-                hip.layernorm(ao_q, *ln("norm1"), 1e-5, B * NT, C, out_f32=queries)
-            else:
-                hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=tq)
-                hip.split_f32(queries, tk)
-                self._attn(L + "self_attn", tq, tq, tk, B, NT, NT, ao_q)
-                hip.layernorm(queries, *ln("norm1"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries)
+            if i > 0:                                                    # self attention (:177-180); layer 0's is in cst["q0"]
+                qkv = ws.f32("sa_qkv", B * NT, 3 * C)
+                self._bgemm(queries_h, self.m[L + "self_qkv"], B, NT, qkv, cst[L + "self_qkv"])
+                token_attn(L + "self_attn", qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], NT, ln("norm1"))
             # tokens -> image (:183-187)
-            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
-            hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
-            hip.split_f32(keys, vh)
-            self._attn(L + "cross_attn_token_to_image", qh, kh, vh, B, NT, T, ao_q)
-            hip.layernorm(queries, *ln("norm2"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries)
+            tokens_to_image(L + "cross_attn_token_to_image", cst[L + "t2i_q"], self.m[L + "t2i_kv"], cst[L + "t2i_kv"], ln("norm2"))
             # tokens -> cond (:189-193)
-            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
-            self._attn(L + "cross_attn_token_to_cond", qh, cond_k, cond_v, B, NT, 2, ao_q)
-            hip.layernorm(queries, *ln("norm2_cond"), 1e-5, B * NT, C, add=ao_q, add_rows=B * NT, out_f32=queries,
-                          out_h2=qh)
+            name = L + "cross_attn_token_to_cond"
+            I = self.lin[name + ".q_proj"].N
+            qp = ws.f32("t_q", B * NT, I)
+            self._bgemm(queries_h, self.lin[name + ".q_proj"], B, NT, qp, cst[L + "t2c_q"])
+            j = self.cond_slot[name]
+            token_attn(name, qp, ck[:, j * I:(j + 1) * I], cv[:, j * I:(j + 1) * I], 2, ln("norm2_cond"))
             # MLP (:196-198)
-            self.gemm(qh, self.lin[L + "mlp.lin1"], B * NT, out_h2=hidh, act=ACT_RELU)
-            self.gemm(hidh, self.lin[L + "mlp.lin2"], B * NT, out_f32=mo)
-            hip.layernorm(queries, *ln("norm3"), 1e-5, B * NT, C, add=mo, add_rows=B * NT, out_f32=queries)
-            # image -> cond (:201-205): q = keys + pe, k = 2*cond, v = cond
-            self._attn(L + "cross_attn_image_to_cond", kh, cond_k, cond_v, B, T, 2, ao_k)
-            hip.layernorm(keys, *ln("norm4_cond"), 1e-5, B * T, C, add=ao_k, add_rows=B * T, out_f32=keys)
-            # image -> tokens (:208-212)
-            hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
-            hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
-            hip.split_f32(queries, tq)
-            self._attn(L + "cross_attn_image_to_token", kh, qh, tq, B, T, NT, ao_k)
-            hip.layernorm(keys, *ln("norm4"), 1e-5, B * T, C, add=ao_k, add_rows=B * T, out_f32=keys)
-        # final token -> image attention (:103-107)
-        hip.add_rows(queries, self.tokens, NT, B * NT, C, out_h2=qh)
-        hip.add_rows(keys, self.pe, T, B * T, C, out_h2=kh)
-        hip.split_f32(keys, vh)
-        self._attn("transformer.final_attn_token_to_image", qh, kh, vh, B, NT, T, ao_q)
-        hs = ws.f32("hs", B * NT, C)
-        hip.layernorm(queries, *self.ln["transformer.norm_final_attn"], 1e-5, B * NT, C, add=ao_q, add_rows=B * NT,
-                      out_f32=hs)
+            self.gemm(queries_h, self.lin[L + "mlp.lin1"], B * NT, out_h2=hidh, act=ACT_RELU)
+            self.gemm(hidh, self.lin[L + "mlp.lin2"], B * NT, residual=queries, out_f32=ao_q)
+            hip.layernorm(ao_q, *ln("norm3"), 1e-5, B * NT, C, out_f32=queries, out_h2=queries_h)
+            # image -> cond (:201-205)
+            name = L + "cross_attn_image_to_cond"
+            j = self.cond_slot[name]
+            image_attn(name, cst[L + "i2c_q"], ck[:, j * I:(j + 1) * I], cv[:, j * I:(j + 1) * I], 2, ln("norm4_cond"))
+            # image -> tokens (:208-212): k = queries + token pe, v = queries
+            name = L + "cross_attn_image_to_token"
+            tkv = ws.f32("t_kv", B * NT, 2 * I)
+            self._bgemm(queries_h, self.m[L + "i2t_kv"], B, NT, tkv, cst[L + "i2t_kv"])
+            image_attn(name, cst[L + "i2t_q"], tkv[:, :I], tkv[:, I:], NT, ln("norm4"))
+        # final token -> image attention (:103-107); hs = the LayerNorm's output, f32 + h2
+        tokens_to_image("transformer.final_attn_token_to_image", cst["fin_q"], self.m["fin_kv"], cst["fin_kv"],
+                        self.ln["transformer.norm_final_attn"])
+        hs, hs_h = queries, queries_h
         # :167-170 upscaling + edge feature head
         HW = 16 * T
         m1 = ws.f32("mf_1", B * HW, C // 4)
         edge_emb = ws.f32("edge_emb", B * HW, C // 8)
         if implicit_conv_ok(C // 8):                                 # both 3x3 convolutions as implicit GEMMs
             up_h = ws.h2("upscaled_h", B * HW, C // 8)
-            up = self._upscale(vh, B, G, "output_upscaling", True, ws.f32("upscaled", B * HW, C // 8), out_h2=up_h)
+            up = self._upscale(keys_h, B, G, "output_upscaling", True, ws.f32("upscaled", B * HW, C // 8), out_h2=up_h)
             self.gemm(up_h, self.mf[0], B * HW, out_f32=m1, conv3x3=(4 * G, 4 * G, C // 8))
             m1h = ws.h2("mf_1h", B * HW, C // 4)
             hip.layernorm(m1, *self.ln["embedding_maskfeature.1"], 1e-6, B * HW, C // 4, act=ACT_GELU, out_h2=m1h)
             self.gemm(m1h, self.mf[1], B * HW, residual=edge_feat, out_f32=edge_emb, conv3x3=(4 * G, 4 * G, C // 4))
         else:
-            up = self._upscale(vh, B, G, "output_upscaling", True, ws.f32("upscaled", B * HW, C // 8))
+            up = self._upscale(keys_h, B, G, "output_upscaling", True, ws.f32("upscaled", B * HW, C // 8))
             col1 = ws.h2("mf_col1", B * HW, 9 * (C // 8))
             hip.im2col3x3(up, B, 4 * G, 4 * G, C // 8, col1)
             self.gemm(col1, self.mf[0], B * HW, out_f32=m1)
@@ -593,14 +674,13 @@ class MaskDecoder(_Base):
             col2 = ws.h2("mf_col2", B * HW, 9 * (C // 4))
             hip.im2col3x3(m1, B, 4 * G, 4 * G, C // 4, col2)
             self.gemm(col2, self.mf[1], B * HW, residual=edge_feat, out_f32=edge_emb)
-        # :172-186 hyper-network rows actually used: mask token 0 (hs row 1) and edge token (hs row 5)
+        # :172-186 hyper-network rows actually used: mask token 0 (hs row 1) and edge token (hs row 5), read in place from the h2
+        # planes of hs (row b * NT + token: pointer offset + row pitch NT * C)
         hyper = ws.f32("hyper", B, 5, C // 8)
-        row, rowh = ws.f32("h_row", B, C), ws.h2("h_rowh", B, C)
         t1, t2 = ws.h2("h_t1", B, C), ws.h2("h_t2", B, C)
-        for tok_row, mlp, slot in ((1, "output_hypernetworks_mlps.0", 0), (5, "edge_mlp", 4)):
-            hip.gather_rows(hs, B, NT, C, None, tok_row, row)
-            hip.split_f32(row, rowh)
-            self.gemm(rowh, self.lin[mlp + ".layers.0"], B, out_h2=t1, act=ACT_RELU)
+        for tok_row, mlp, slot in ((1, "output_hypernetworks_mlps.0", 0), (NT - 1, "edge_mlp", 4)):
+            rowh = H2(hs_h.t[:, tok_row:])
+            self.gemm(rowh, self.lin[mlp + ".layers.0"], B, lda=NT * C, out_h2=t1, act=ACT_RELU)
             self.gemm(t1, self.lin[mlp + ".layers.1"], B, out_h2=t2, act=ACT_RELU)
             self.gemm(t2, self.lin[mlp + ".layers.2"], B, out_f32=hyper[:, slot], ldo=5 * (C // 8))
         low = ws.f32("low", B, HW)

@@ -24,9 +24,9 @@ EXPORTS = [
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
-    "cvlm_ln_stats_merge",
+    "cvlm_ln_stats_merge", "cvlm_small_attention_h2",
 ]
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class GemmArgs(C.Structure):
@@ -384,12 +384,18 @@ def attention_workspace_bytes(B: int, S: int, heads: int, hd: int, *, mode: int 
     return int(load().cvlm_attention_workspace_bytes(C.byref(a)))
 
 
-def small_attention(q, k, v, out, B: int, nq: int, nk: int, heads: int, hd: int) -> None:
+def small_attention(q, k, v, out, B: int, nq: int, nk: int, heads: int, hd: int, out_h2: Optional[H2] = None) -> None:
+    """q f32 [B*nq][>= heads*hd], k / v f32 [B*nk][>= heads*hd]: 2-D tensors (or column blocks of one: the row pitch is taken from
+    `.stride(0)`); out f32 [B*nq][heads*hd] and / or out_h2 planes of that shape."""
     ld = heads * hd
-    _check(load().cvlm_small_attention(
-        C.c_void_p(q.data_ptr()), C.c_int64(ld), C.c_void_p(k.data_ptr()), C.c_int64(ld), C.c_void_p(v.data_ptr()),
-        C.c_int64(ld), C.c_void_p(out.data_ptr()), C.c_int64(ld), C.c_int32(B), C.c_int32(nq), C.c_int32(nk),
-        C.c_int32(heads), C.c_int32(hd), C.c_void_p(_stream())), "cvlm_small_attention")
+    pitch = lambda t: t.stride(-2) if t.dim() >= 2 else ld
+    for t in (q, k, v):
+        assert t.dtype == torch.float32 and t.stride(-1) == 1
+    _check(load().cvlm_small_attention_h2(
+        C.c_void_p(q.data_ptr()), C.c_int64(pitch(q)), C.c_void_p(k.data_ptr()), C.c_int64(pitch(k)), C.c_void_p(v.data_ptr()),
+        C.c_int64(pitch(v)), C.c_void_p(_p(out)), C.c_int64(ld), C.c_void_p(out_h2.hi.data_ptr() if out_h2 is not None else None),
+        C.c_void_p(out_h2.lo.data_ptr() if out_h2 is not None else None), C.c_int64(ld), C.c_int32(B), C.c_int32(nq), C.c_int32(nk),
+        C.c_int32(heads), C.c_int32(hd), C.c_void_p(_stream())), "cvlm_small_attention_h2")
 
 
 def dense_pe(gauss: torch.Tensor, size: int, Cc: int, out: torch.Tensor) -> None:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 6
+#define CVLM_ABI_VERSION 7
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -213,6 +213,14 @@ int64_t cvlm_attention_workspace_bytes(const cvlm_attn_args* args);
 int cvlm_small_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                          float* out, int64_t ldo, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
                          void* stream);
+/* ABI 7: the same with the result also / only as h2 planes [B][nq][heads*hd] (row pitch ldoh halves) -- the operand of the
+ * out_proj GEMM that follows every attention of the two-way transformer (transformer_maskdecoder_edge.py:268-271), so no
+ * cvlm_split_f32 launch sits between them.  `out` and (out_hi, out_lo) are each optional, one of them is required.  q / k / v may
+ * be column blocks of one wider matrix (merged q|k|v projection): pass the block's first column and the matrix's row pitch.
+ * hd = 16 or 32; row pitches multiples of 4, bases 16-byte aligned. */
+int cvlm_small_attention_h2(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* out, int64_t ldo,
+                            void* out_hi, void* out_lo, int64_t ldoh, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
+                            void* stream);
 
 /* Dense positional encoding (models/sam_maskdecoder_edge.py:90-110): gauss f32 [2][C/2] ->
  * out f32 [size*size][C] (token-major: row = y*size+x). */

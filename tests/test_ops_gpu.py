@@ -736,7 +736,8 @@ def test_attention_window_relpos(hip, G, split, hm):
 
 
 def test_small_attention(hip):
-    for (Bn, nq, nk, Hh, hd) in [(2, 6, 400, 8, 16), (2, 400, 6, 8, 16), (2, 6, 6, 8, 32), (1, 400, 2, 8, 16)]:
+    for (Bn, nq, nk, Hh, hd) in [(2, 6, 400, 8, 16), (2, 400, 6, 8, 16), (2, 6, 6, 8, 32), (1, 400, 2, 8, 16), (1, 6, 4096, 8, 16),
+                                 (2, 5, 1300, 8, 32)]:
         D = Hh * hd
         q, k, v = rnd(Bn, nq, D, seed=25), rnd(Bn, nk, D, seed=26), rnd(Bn, nk, D, seed=27)
         out = torch.empty(Bn, nq, D, device="cuda")
@@ -744,6 +745,22 @@ def test_small_attention(hip):
         sp = lambda t, n: t.double().reshape(Bn, n, Hh, hd).transpose(1, 2)
         ref = ref_attention(sp(q, nq), sp(k, nk), sp(v, nk), 1 / math.sqrt(hd)).transpose(1, 2).reshape(Bn, nq, D)
         assert relerr(out, ref) < 3e-6
+        # ABI 7: q | k | v as column blocks of one merged projection (row pitch 3 D), the result as h2 planes only / as both
+        if nq == nk:
+            qkv = torch.cat([q, k, v], dim=-1).reshape(Bn * nq, 3 * D).cuda().contiguous()
+            blocks = (qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:])
+        else:
+            kv = torch.cat([k, v], dim=-1).reshape(Bn * nk, 2 * D).cuda().contiguous()
+            blocks = (q.reshape(Bn * nq, D).cuda(), kv[:, :D], kv[:, D:])
+        oh = hip.H2.empty(Bn * nq, D)
+        hip.small_attention(*blocks, None, Bn, nq, nk, Hh, hd, out_h2=oh)
+        assert relerr(oh.float().reshape(Bn, nq, D), ref) < 3e-6
+        out2, oh2 = torch.empty(Bn * nq, D, device="cuda"), hip.H2.empty(Bn * nq, D)
+        hip.small_attention(*blocks, out2, Bn, nq, nk, Hh, hd, out_h2=oh2)
+        assert torch.equal(out2.reshape(Bn, nq, D), out) and torch.equal(oh2.t, oh.t)
+    with pytest.raises(RuntimeError):                                  # head dims other than the decoder's two are refused, loudly
+        hip.small_attention(torch.zeros(1, 2, 24, device="cuda"), torch.zeros(1, 2, 24, device="cuda"), torch.zeros(1, 2, 24, device="cuda"),
+                            torch.empty(1, 2, 24, device="cuda"), 1, 2, 2, 1, 24)
 
 
 def test_patchify_and_im2col(hip):
