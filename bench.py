@@ -54,7 +54,7 @@ ENCODER_TFLOP_PER_IMAGE = {1024: 5.681, 1536: 13.712}
 # Measured on this part (tools/power_roofline.py, profiles/r02_power_roofline.log): an MFMA-only loop (16x16x32 f16, random
 # operands, every CU) settles at 1.88 PF at the 1400-W socket cap (sclk 1.95 GHz of 2.4): what the matrix pipe can sustain.
 MFMA_F16_POWER_ROOFLINE_TFLOPS = 1880.0
-TRAFFIC_FILES = ("r03_gemm_traffic.json", "r02_gemm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest first
+TRAFFIC_FILES = ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest first
 
 
 def under_profiler() -> bool:
@@ -315,7 +315,11 @@ class Roofline:
             e0.record()
             orig(a, w, M, N, K, **kw)
             e1.record()
-            records.append((2.0 * M * N * K * kw.get("batch", 1), e0, e1))
+            # algorithmic bytes of the launch: both operands once (4 B per element: two fp16 planes), the residual if any, every output
+            nb = kw.get("batch", 1)
+            by = 4.0 * (M * K + N * K) * nb + (4.0 * M * N * nb if (kw.get("residual") is not None or kw.get("residual_h2") is not None) else 0.0) \
+                + 4.0 * M * N * nb * ((kw.get("out_f32") is not None) + (kw.get("out_h2") is not None))
+            records.append((2.0 * M * N * K * nb, e0, e1, by))
 
         def timed_attn(qkv, o, Bn, S, heads, hd, **kw):
             mode = kw.get("mode", 0)
@@ -353,6 +357,7 @@ class Roofline:
                          f"(x2 gfx950 correction) and WRITE_SIZE passes of the default command (profiles/{tname})")
                 break
         flops = sum(r[0] for r in records)
+        abytes = sum(r[3] for r in records)
         ms = sum(r[1].elapsed_time(r[2]) for r in records)
         achieved = flops / (ms * 1e-3) / 1e12
         secondary = []
@@ -377,6 +382,12 @@ class Roofline:
         return {"kernel": "gemm_nt_kernel<split=%d>" % self.split, "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
+                "algorithmic_bytes_per_launch": round(abytes / len(records)),
+                "traffic_over_algorithmic": round(traffic / (abytes / len(records)), 3) if traffic else None,
+                "traffic_explained": "each of the 8 XCD L2s pulls every weight panel it multiplies (weights x 8: the price of partitioning "
+                                     "the ROWS over the XCDs, which keeps the 5-30x larger activation to ~2 fetches); the re-fetches are "
+                                     "served by the 256-MB infinity cache, and HBM + fabric are < 2 % of a launch's energy "
+                                     "(profiles/r02_power_gemm_parts.log; DESIGN.md section 6)",
                 "launches": len(records), "avg_launch_us": round(1e3 * ms / len(records), 2),
                 "algorithmic_gflop_per_launch": round(flops / len(records) / 1e9, 3),
                 "gemm_share_of_step": round(ms * 1e-3 / nrep / step_seconds, 3),
