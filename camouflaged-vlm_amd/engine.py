@@ -1069,8 +1069,8 @@ class Cascade(_Base):
     # batch is served.
     def _fold_guard_check(self) -> None:
         g = self._guard
-        if g is None or not g[1].query():
-            return
+        if g is None or torch.cuda.is_current_stream_capturing() or not g[1].query():
+            return                                                   # (an event query would invalidate a hipGraph capture)
         self._guard = None
         refused = int(g[0][0]) + int(g[0][1])
         if refused > self._refused_seen:
@@ -1086,6 +1086,8 @@ class Cascade(_Base):
     def _fold_guard_arm(self, stream) -> None:
         if not ((self.encoder.ln_fold and not self.encoder.fold_disabled) or (self.clip.ln_fold and not self.clip.fold_disabled)):
             return
+        if torch.cuda.is_current_stream_capturing():                 # a captured step carries no host-side check: the caller of a
+            return                                                   # graph reads ws.gemm_errors() itself (tools/graph_step.py)
         if self._guard_host is None:
             self._guard_host = torch.zeros(2, dtype=torch.int32).pin_memory()
         with torch.cuda.stream(stream):
