@@ -206,6 +206,9 @@ def parse():
                          "evaluation loop end to end (test_ovcos_maskdecoder_edge.py:89-141): uint8 images + uint8 ground truth on the "
                          "host -> H2D -> GPU preprocessing (N1) -> infer_test -> stage 2 -> Classification + mask_to_u8 + "
                          "OVCOSMetricer on the device (N2), one read-back of the metric dict at the end")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="--surface evalloop: the engine's pipelined serving loop underneath (decoder / stage 2 of batch i under the encoder "
+                         "of batch i + 1, evaluation tail on a third stream) instead of the reference's call-by-call order")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run CLIP pass 1 after the SAM encoder instead of on a side stream beneath it (profiling runs: "
                          "co-running kernels stretch each other's durations)")
@@ -455,11 +458,12 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
     setup_s = time.time() - t0
 
     # ---- the timed loop: W warm-up steps, K timed steps, the final read-back of the metric dict INSIDE the timed region
-    loop = DeviceEvalLoop(model, names)
+    loop = DeviceEvalLoop(model, names, pipelined=args.pipelined)
     for i in range(args.warmup):
         loop.step(*batch(i))
+    loop.results()
     torch.cuda.synchronize()
-    loop = DeviceEvalLoop(model, names, timed=True)
+    loop = DeviceEvalLoop(model, names, timed=True, pipelined=args.pipelined)
     sampler.start()
     wall0 = time.time()
     try:
@@ -489,7 +493,9 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
     parity = {"outputs_finite": finite, "parity_checked": False, "images": n_all, "gemm_handoff_errors": handoff,
               "timed_loop_dict_equals_first_pass": same_run,
               "device_metrics": {k: round(float(v), 6) for k, v in dev_metrics.items()}, "device_classification": dev_cls}
-    parity["ok"] = bool(finite and handoff == 0 and (same_run is None or same_run < 1e-12))
+    # pipelined: stage 2 shares one CLIP forward with the next batch's pass 1 -- other K-splits, other fp32 summation order: a mask level
+    # may move on a handful of pixels
+    parity["ok"] = bool(finite and handoff == 0 and (same_run is None or same_run < (1e-4 if args.pipelined else 1e-12)))
 
     # ---- cpu_baseline leg: the same loop's two tails as the reference runs them, on the host -- Pillow + numpy preprocessing (what
     # torchvision's transforms call, datasets/wrappers.py:22-62) and D2H + cv2-style resize + the six numpy metric classes
@@ -577,7 +583,7 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
                                    "sizes -> GpuPreprocess (N1) -> infer_test -> torch.sigmoid -> F.interpolate(336) -> clip_model -> "
                                    "Classification.process + mask_to_u8 + OVCOSMetricer.step on the device (N2); metric dict read back once, "
                                    "inside the timed region" if args.geometry == "demo" else "tiny geometry (debug)",
-                       "images_per_step": B, "distinct_images": n_items, "image_sizes": sorted(set(d[0].shape[:2] for d in data)),
+                       "images_per_step": B, "distinct_images": n_items, "pipelined": bool(args.pipelined), "image_sizes": sorted(set(d[0].shape[:2] for d in data)),
                        "precision": args.precision, "setup_seconds": round(setup_s, 1)},
             "section_ms_per_image": per_img, "section_share_of_gpu_time": shares, "section_host_issue_ms_per_image": host_per_img,
             "n1_plus_n2_plus_h2d_share": round(tail_ms / (tail_ms + per_img["path_infer_test_stage2"]), 4),

@@ -26,9 +26,12 @@ SECTIONS = ("h2d", "n1_preprocess", "path_infer_test_stage2", "n2_eval_tail")
 
 class DeviceEvalLoop:
     def __init__(self, model, class_names: Sequence[str], metric_names=("sm", "wfm", "mae", "fm", "em", "iou"),
-                 clip_mask_convention: str = "wrapper", timed: bool = False):
+                 clip_mask_convention: str = "wrapper", timed: bool = False, pipelined: bool = False):
         """model: the drop-in `models.make(...)` object (on the GPU, CLIP loaded); class_names: the test split's classes
-        (test_ovcos_maskdecoder_edge.py:77-87).  timed: record HIP events around the four sections of every step."""
+        (test_ovcos_maskdecoder_edge.py:77-87).  timed: record HIP events around the four sections of every step.
+        pipelined: the serving loop of `engine.Cascade.cascade(pipelined=True)` underneath -- decoder and stage 2 of batch i run under
+        the encoder of batch i + 1, and the evaluation tail of batch i runs on a third stream once its class scores exist (one call
+        later); `results()` flushes.  Same numbers up to the fp32 summation order of the fused CLIP forward."""
         self.model = model
         self.device = model.no_mask_embed.weight.device
         if self.device.type != "cuda":
@@ -40,6 +43,9 @@ class DeviceEvalLoop:
         self.evaluator = DeviceClassification({i: n for i, n in enumerate(self.class_names)}, device=str(self.device))
         self.metricer = DeviceMetricer(self.class_names, metric_names)
         self.timed = timed
+        self.pipelined = pipelined
+        self._tail_stream: Optional[torch.cuda.Stream] = None
+        self._owed = None                                             # pipelined: (masks, pred, logits, gts, labels) of the batch whose tail is still to run
         self.events: List[list] = []
         self.images = 0
         self.last: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, List[torch.Tensor]]] = None
@@ -69,6 +75,8 @@ class DeviceEvalLoop:
         clip_image = torch.cat([self.pre.clip_input(t) for t in imgs])
         clip_mask = self.pre.clip_mask(len(imgs), self.convention)
         self._mark(marks)
+        if self.pipelined:
+            return self._step_pipelined(inp, clip_image, clip_mask, gts, labels, marks)
         # the path, with the script's own glue (test_ovcos_maskdecoder_edge.py:102-113)
         pred_mask = self.model.infer_test(inp, clip_image, clip_mask)
         prob = torch.sigmoid(pred_mask)
@@ -85,8 +93,43 @@ class DeviceEvalLoop:
         self.images += len(imgs)
         self.last = (pred_mask, pred_1, score, masks_u8)
 
+    # ---- pipelined form ------------------------------------------------------------------------------------------------------------
+    def _run_tail(self, owed, after: torch.cuda.Event) -> None:
+        """N2 of one batch on the tail stream, behind `after` (the side-stream event that covers its masks AND its class scores)"""
+        masks, pred, logits, gts, labels = owed
+        tail = self._tail_stream
+        tail.wait_event(after)
+        with torch.cuda.stream(tail):
+            self.evaluator.process(logits, labels)
+            same = pred.to(torch.int64) == labels.to(torch.int64)
+            self.metricer.step_batch(masks, gts, same)
+        for t in (masks, pred, logits, labels, *gts):
+            t.record_stream(tail)
+
+    def _step_pipelined(self, inp, clip_image, clip_mask, gts, labels, marks) -> None:
+        cas = self.model.cascade()
+        if self._tail_stream is None:
+            self._tail_stream = torch.cuda.Stream(device=self.device)
+        masks, pred, logits = cas.cascade(inp, clip_image, clip_mask, pipelined=True)
+        done = cas._done[cas._parity ^ 1]                             # side stream: this batch's decoder is through -- and, in front of it,
+        self._mark(marks)                                             # the fused CLIP forward that filled the PREVIOUS batch's pred / logits
+        if self._owed is not None:
+            self._run_tail(self._owed, done)
+        self._owed = (masks, pred, logits, gts, labels)
+        self._mark(marks)
+        if marks is not None:
+            self.events.append(marks)
+        self.images += int(inp.shape[0])
+        self.last = None
+
     def results(self) -> Tuple[Dict[str, float], Dict[str, float]]:
         """-> (`metricer.show(num_bits=None)` dict, `evaluator.evaluate()` dict): the one read-back of the loop."""
+        if self.pipelined and self._owed is not None:
+            cas = self.model.cascade()
+            cas.flush()                                               # the last batch's stage 2 (no-op when nothing is owed there)
+            self._run_tail(self._owed, cas._clip_done if cas._clip_done is not None else cas._done[cas._parity ^ 1])
+            self._owed = None
+        torch.cuda.synchronize(self.device)
         return self.metricer.show(num_bits=None), dict(self.evaluator.evaluate())
 
     def section_ms(self) -> Dict[str, float]:
