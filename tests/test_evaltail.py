@@ -329,3 +329,12 @@ def test_dropin_recorder_surface(gold):
     res = m.show(num_bits=None)
     assert abs(res["sm"] - one["sm"] / 2) < TOL and abs(res["mae"] - (one["mae"] + 1) / 2) < TOL
     assert isinstance(Classification(), E.DeviceClassification)
+    # the reference's loop hands numpy arrays over (test_ovcos_maskdecoder_edge.py:130-136): same numbers, same asserts
+    n = recorder.OVCOSMetricer(["cat", "dog"])
+    n.step(pre=pre, gt=gt, pre_cls="cat", gt_cls="cat", gt_path="x.png")
+    n.step(pre=pre, gt=gt, pre_cls="cat", gt_cls="dog")
+    assert n.show(num_bits=None) == res
+    with pytest.raises(AssertionError):
+        n.step(pre=pre.astype(np.float32), gt=gt, pre_cls="cat", gt_cls="cat")
+    with pytest.raises(AssertionError):
+        n.step(pre=pre[:-1], gt=gt, pre_cls="cat", gt_cls="cat")
