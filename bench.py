@@ -455,6 +455,7 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
         kept.append((loop.last[0].clone(), loop.last[1].clone(), loop.last[2].clone(), [m.clone() for m in loop.last[3]]))
     torch.cuda.synchronize()
     dev_metrics, dev_cls = loop.results()
+    dev_cod = loop.cod_results()
     setup_s = time.time() - t0
 
     # ---- the timed loop: W warm-up steps, K timed steps, the final read-back of the metric dict INSIDE the timed region
@@ -492,7 +493,8 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
     same_run = max(abs(timed_metrics[k] - dev_metrics[k]) for k in dev_metrics) if args.steps % nb == 0 and args.steps >= nb else None
     parity = {"outputs_finite": finite, "parity_checked": False, "images": n_all, "gemm_handoff_errors": handoff,
               "timed_loop_dict_equals_first_pass": same_run,
-              "device_metrics": {k: round(float(v), 6) for k, v in dev_metrics.items()}, "device_classification": dev_cls}
+              "device_metrics": {k: round(float(v), 6) for k, v in dev_metrics.items()}, "device_classification": dev_cls,
+              "device_calc_cod": {k: round(float(v), 6) for k, v in dev_cod.items()}}
     # pipelined: stage 2 shares one CLIP forward with the next batch's pass 1 -- other K-splits, other fp32 summation order: a mask level
     # may move on a handful of pixels
     parity["ok"] = bool(finite and handoff == 0 and (same_run is None or same_run < (1e-4 if args.pipelined else 1e-12)))
@@ -507,8 +509,10 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
     if not args.no_cpu_baseline:
         from oracle import metrics_oracle as MO
         from oracle import preprocess_oracle as PO
+        from camouflaged_vlm_amd.preprocess import nearest_indices
         host_cores = os.cpu_count() or 1
         torch.set_num_threads(min(16, host_cores))
+        cods = []
         try:
             from PIL import Image
             im_mean, im_std = loop.pre.im_mean.cpu().numpy(), loop.pre.im_std.cpu().numpy()
@@ -544,6 +548,9 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
                 lgj = logits[j, 0].cpu().numpy()                         # the 4-MB D2H of the float mask (:116)
                 u8_orc = MO.mask_to_u8(lgj, *gt.shape)
                 steps_b.append(MO.ovcos_metrics(u8_orc, gt, same))
+                # :105 calc_cod(pred_mask, batch['gt']): the float map against the NEAREST-resized ground truth (wrappers.py:29-32)
+                gt_s = (gt[nearest_indices(gt.shape[0], g.inp_size)][:, nearest_indices(gt.shape[1], g.inp_size)] / 255.0).astype(np.float32)
+                cods.append(MO.calc_cod(MO.sigmoid_f32(lgj)[None, None], gt_s[None, None]))
                 t_n2.append(time.perf_counter() - tc)
                 u8_dev = masks_u8[j].cpu().numpy()
                 d = np.abs(u8_dev.astype(np.int16) - u8_orc.astype(np.int16))
@@ -557,20 +564,22 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
         im0 = data[1][0]
         n1_equal = bool(np.array_equal(loop.pre.sam_input(torch.from_numpy(im0).to(dev)).cpu().numpy()[0], PO.sam_input(im0, g.inp_size)) and
                         np.array_equal(loop.pre.clip_input(torch.from_numpy(im0).to(dev)).cpu().numpy()[0], PO.clip_input(im0, c.image_resolution)))
+        cod_err = max(abs(dev_cod[key] - float(np.mean([cdv[k] for cdv in cods]))) for k, key in enumerate(("sm", "em", "wfm", "mae")))
         parity.update({"parity_checked": True, "metric_dict_vs_oracle_on_device_masks": err_a, "metric_dict_vs_oracle_from_logits": err_b,
+                       "calc_cod_vs_oracle": cod_err, "tolerance_calc_cod": 1e-5,
                        "tolerance_on_device_masks": 1e-9, "tolerance_from_logits": 1e-4, "mask_u8_max_level_diff": worst_levels,
                        "mask_u8_max_fraction_of_pixels_moved": frac_moved, "classification_err": cls_err, "pred_is_argmax": bool(cls_ok),
                        "n1_bit_exact_vs_pillow_pinned_oracle": n1_equal,
                        "reference": "oracle/metrics_oracle.py = the reference's OVCOSMetricer / sod_metric classes (bit-exact pin: "
                                     "tests/golden/evaltail.npz); cv2.resize restated, unpinned"})
         parity["ok"] = bool(parity["ok"] and err_a <= 1e-9 and err_b <= 1e-4 and worst_levels <= 1 and frac_moved < 1e-3 and cls_err < 1e-9 and
-                            cls_ok and n1_equal)
+                            cls_ok and n1_equal and cod_err <= 1e-5)
         n1_ms, n2_ms = 1e3 * sum(t_n1) / n_all, 1e3 * sum(t_n2) / n_all
         gpu_path_ms = per_img["path_infer_test_stage2"]
         cpu = {"value": round(1e3 / (gpu_path_ms + n1_ms + n2_ms), 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                "sample": f"all {n_all} images of the synthetic split: CPU preprocessing {n1_ms:.1f} ms/image ({n1_kind}), CPU evaluation tail "
-                         f"{n2_ms:.1f} ms/image (D2H of the float mask + cv2-style resize + the six numpy metric classes of "
-                         f"oracle/metrics_oracle.py), one process, serial with the GPU path ({gpu_path_ms:.2f} ms/image) as in the reference's "
+                         f"{n2_ms:.1f} ms/image (D2H of the float mask + cv2-style resize + the six numpy metric classes + calc_cod's four on "
+                         f"the {g.inp_size}^2 float map, oracle/metrics_oracle.py), one process, serial with the GPU path ({gpu_path_ms:.2f} ms/image) as in the reference's "
                          "loop body (its DataLoader workers would hide the preprocessing share, not the tail)",
                "n1_cpu_ms_per_image": round(n1_ms, 2), "n2_cpu_ms_per_image": round(n2_ms, 2),
                "cpu_model": cpu_model(), "host_cores": host_cores}
@@ -581,7 +590,7 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
             "dtype": DTYPE_NAMES[args.precision], "data": "synthetic",
             "config": {"workload": f"evaluation loop, batch {B} (test_ovcos_maskdecoder_edge.py:89-141): H2D of uint8 images / masks of mixed "
                                    "sizes -> GpuPreprocess (N1) -> infer_test -> torch.sigmoid -> F.interpolate(336) -> clip_model -> "
-                                   "Classification.process + mask_to_u8 + OVCOSMetricer.step on the device (N2); metric dict read back once, "
+                                   "calc_cod + Classification.process + mask_to_u8 + OVCOSMetricer.step on the device (N2); metric dicts read back once, "
                                    "inside the timed region" if args.geometry == "demo" else "tiny geometry (debug)",
                        "images_per_step": B, "distinct_images": n_items, "pipelined": bool(args.pipelined), "image_sizes": sorted(set(d[0].shape[:2] for d in data)),
                        "precision": args.precision, "setup_seconds": round(setup_s, 1)},

@@ -196,6 +196,128 @@ __global__ __launch_bounds__(256) void wfm_levels_kernel(const unsigned* __restr
     if (v == 0) { lohi[2 * n] = lo; lohi[2 * n + 1] = hi; }
 }
 
+// Where the weighted F-measure takes the prepared prediction of a pixel from (`prepare_data`, sod_metric.py:12-26: v / 255, min-max
+// normalised), as a double:
+//   WfmU8:   a uint8 mask and the lowest / highest level present (OVCOSMetricer.step: the 256 levels, normalised per level);
+//   WfmProb: a FLOAT probability map and its min / max (utils.calc_cod feeds `y_pred * 255` as float32: no uint8 step) -- the same
+//            float32 operations numpy performs: p * 255, / 255, (v - min) / (max - min).
+__device__ __forceinline__ float cod_pred(float p) { return __fdiv_rn(__fmul_rn(p, 255.0f), 255.0f); }
+__device__ __forceinline__ float cod_norm(float p, float mn, float mx) {
+    const float v = cod_pred(p);
+    return mx != mn ? __fdiv_rn(__fsub_rn(v, mn), __fsub_rn(mx, mn)) : v;
+}
+struct WfmU8 {
+    const uint8_t* pre; const int* lohi;
+    struct Img {
+        const uint8_t* pre; int lo, hi;
+        __device__ __forceinline__ double operator()(int64_t i) const { return wfm_norm(pre[i], lo, hi); }
+    };
+    __device__ __forceinline__ Img image(int n) const { return Img{pre, lohi[2 * n], lohi[2 * n + 1]}; }
+};
+struct WfmProb {
+    const float* prob; const float* minmax;
+    struct Img {
+        const float* prob; float mn, mx;
+        __device__ __forceinline__ double operator()(int64_t i) const { return (double)cod_norm(prob[i], mn, mx); }
+    };
+    __device__ __forceinline__ Img image(int n) const { return Img{prob, minmax[2 * n], minmax[2 * n + 1]}; }
+};
+
+// ---- utils.calc_cod on float probability maps (utils.py:143-165) -----------------------------------------------------------------
+constexpr int COD_PARTS = 64;
+// per-workgroup (min, max) of fl(fl(p * 255) / 255) over a share of image n -> partial f32 [N][COD_PARTS][2]
+__global__ __launch_bounds__(256) void cod_minmax_kernel(const float* __restrict__ prob, int64_t hw, float* __restrict__ partial) {
+    const int n = blockIdx.y;
+    const float* p = prob + (int64_t)n * hw;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)COD_PARTS * 256) {
+        const float v = cod_pred(p[i]);
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    __shared__ float red[4][2];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = mn; red[threadIdx.x >> 6][1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((int64_t)n * COD_PARTS + blockIdx.x) * 2] = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+        partial[((int64_t)n * COD_PARTS + blockIdx.x) * 2 + 1] = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+    }
+}
+
+// every workgroup folds the COD_PARTS partials of its image (block 0 publishes minmax[n]), then q = uint8(pn * 255): the levels the
+// E-measure's cumulative histograms count (sod_metric.py:420, `(pred * 255).astype(np.uint8)`)
+__global__ __launch_bounds__(256) void cod_quant_kernel(const float* __restrict__ prob, int64_t hw, const float* __restrict__ partial,
+                                                        float* __restrict__ minmax, uint8_t* __restrict__ q) {
+    const int n = blockIdx.y;
+    __shared__ float mm[2];
+    if (threadIdx.x < 64) {
+        float mn = partial[((int64_t)n * COD_PARTS + threadIdx.x) * 2], mx = partial[((int64_t)n * COD_PARTS + threadIdx.x) * 2 + 1];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+        if (threadIdx.x == 0) { mm[0] = mn; mm[1] = mx; if (blockIdx.x == 0) { minmax[2 * n] = mn; minmax[2 * n + 1] = mx; } }
+    }
+    __syncthreads();
+    const float mn = mm[0], mx = mm[1];
+    const float* p = prob + (int64_t)n * hw;
+    uint8_t* o = q + (int64_t)n * hw;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256)
+        o[i] = (uint8_t)(int)__fmul_rn(cod_norm(p[i], mn, mx), 255.0f);
+}
+
+// sums of pn and pn^2 per S-measure quadrant (split at the ground truth's centroid, as joint_hist_kernel) and ground-truth class:
+// partial f64 [N][COD_PARTS][4][2][2]
+__global__ __launch_bounds__(256) void cod_moments_kernel(const float* __restrict__ prob, const uint8_t* __restrict__ gt, int h, int w,
+                                                          const float* __restrict__ minmax, const unsigned long long* __restrict__ stats,
+                                                          double* __restrict__ partial) {
+    const int n = blockIdx.y;
+    const unsigned long long cnt = stats[3 * n];
+    int cx, cy;
+    if (cnt == 0) {
+        cx = (int)rint((double)w / 2.0) + 1; cy = (int)rint((double)h / 2.0) + 1;
+    } else {
+        cx = (int)rint((double)stats[3 * n + 1] / (double)cnt) + 1; cy = (int)rint((double)stats[3 * n + 2] / (double)cnt) + 1;
+    }
+    const float mn = minmax[2 * n], mx = minmax[2 * n + 1];
+    const int64_t hw = (int64_t)h * w;
+    const float* p = prob + (int64_t)n * hw;
+    const uint8_t* g = gt + (int64_t)n * hw;
+    double acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)COD_PARTS * 256) {
+        const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+        const int cell = ((y >= cy ? 2 : 0) + (x >= cx ? 1 : 0)) * 2 + (g[i] > 128 ? 1 : 0);
+        const double v = (double)cod_norm(p[i], mn, mx);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {                                 // branch-free: registers cannot be indexed by `cell`
+            const double m = cell == k ? 1.0 : 0.0;
+            acc[2 * k] += m * v;
+            acc[2 * k + 1] += m * v * v;
+        }
+    }
+    __shared__ double red[4][16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        double a = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16)
+        partial[((int64_t)n * COD_PARTS + blockIdx.x) * 16 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void cod_moments_finalize_kernel(const double* __restrict__ partial, double* __restrict__ out) {
+    const int n = blockIdx.x;
+    if (threadIdx.x < 16) {
+        double a = 0.0;
+        for (int b = 0; b < COD_PARTS; ++b) a += partial[((int64_t)n * COD_PARTS + b) * 16 + threadIdx.x];   // fixed order
+        out[(int64_t)n * 16 + threadIdx.x] = a;
+    }
+}
+
 // Column pass: nearest foreground row inside each column (above-or-at vs below, ties to the smaller row).
 // A workgroup owns 64 columns; the column is cut into segments of 64 rows and a thread keeps the foreground flags of a
 // segment as one 64-bit mask (segments s = ty, ty + 16, ...: h <= 4096).  First / last foreground row of every segment go
@@ -275,8 +397,9 @@ __global__ __launch_bounds__(256) void wfm_colpass_tall_kernel(const uint8_t* __
 // candidates outwards from its own position, left side first, and stops a side once dx^2 alone exceeds the best distance --
 // the same minimum as the full scan in column order, ties to the smaller column: on the left a later (smaller) column
 // replaces an equal distance, on the right only a strictly smaller one does (round 3 scanned all w columns for every pixel).
-__global__ __launch_bounds__(256) void wfm_rowpass_kernel(const uint8_t* __restrict__ pre, const uint8_t* __restrict__ gt, int h,
-                                                          int w, const int* __restrict__ near_y, const int* __restrict__ lohi,
+template <typename SRC>
+__global__ __launch_bounds__(256) void wfm_rowpass_kernel(const SRC src, const uint8_t* __restrict__ gt, int h,
+                                                          int w, const int* __restrict__ near_y,
                                                           int* __restrict__ d2o, double* __restrict__ Et) {
     extern __shared__ int rowbuf[];                                   // candidate column [w] | its dy^2 [w] | its near row [w] | rank [w]
     __shared__ int wave_tot[4], total_c;
@@ -286,7 +409,7 @@ __global__ __launch_bounds__(256) void wfm_rowpass_kernel(const uint8_t* __restr
     int* rank = rowbuf + 3 * w;
     const int n = blockIdx.y, y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)n * h * w;
-    const int lo = lohi[2 * n], hi = lohi[2 * n + 1];
+    const auto val = src.image(n);                                    // val(i): the prepared prediction of pixel i of this image, as a double
     // compaction: thread t owns the columns [t * per, t * per + per)
     const int per = (w + 255) / 256;
     const int c0 = min(tid * per, w), c1 = min(c0 + per, w);
@@ -311,7 +434,7 @@ __global__ __launch_bounds__(256) void wfm_rowpass_kernel(const uint8_t* __restr
         const int64_t i = base + (int64_t)y * w + x;
         if (gt[i] > 128) {
             d2o[i] = 0;
-            Et[i] = fabs(wfm_norm(pre[i], lo, hi) - 1.0);
+            Et[i] = fabs(val(i) - 1.0);
             continue;
         }
         int best = WFM_INF + WFM_INF, bj = -1;
@@ -329,13 +452,14 @@ __global__ __launch_bounds__(256) void wfm_rowpass_kernel(const uint8_t* __restr
             if (d < best) { best = d; bj = j; }
         }
         d2o[i] = best;
-        Et[i] = bj < 0 ? 0.0 : fabs(wfm_norm(pre[base + (int64_t)nry[bj] * w + colx[bj]], lo, hi) - 1.0);
+        Et[i] = bj < 0 ? 0.0 : fabs(val(base + (int64_t)nry[bj] * w + colx[bj]) - 1.0);
     }
 }
 
 // 7x7 Gaussian of Et (zero outside), pixel importance, block partial sums {sum Ew over fg, sum Ew over bg, fg count}
-__global__ __launch_bounds__(256) void wfm_weight_kernel(const uint8_t* __restrict__ pre, const uint8_t* __restrict__ gt, int h,
-                                                         int w, const int* __restrict__ lohi, const int* __restrict__ d2,
+template <typename SRC>
+__global__ __launch_bounds__(256) void wfm_weight_kernel(const SRC src, const uint8_t* __restrict__ gt, int h,
+                                                         int w, const int* __restrict__ d2,
                                                          const double* __restrict__ Et, const double* __restrict__ gauss,
                                                          double* __restrict__ partial) {
     __shared__ double K[49];
@@ -344,7 +468,7 @@ __global__ __launch_bounds__(256) void wfm_weight_kernel(const uint8_t* __restri
     __syncthreads();
     const int n = blockIdx.y;
     const int64_t base = (int64_t)n * h * w, total = (int64_t)h * w;
-    const int lo = lohi[2 * n], hi = lohi[2 * n + 1];
+    const auto val = src.image(n);
     double sfg = 0.0, sbg = 0.0, cfg = 0.0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
@@ -360,7 +484,7 @@ __global__ __launch_bounds__(256) void wfm_weight_kernel(const uint8_t* __restri
             }
         }
         const bool fg = gt[base + i] > 128;
-        const double e = fabs(wfm_norm(pre[base + i], lo, hi) - (fg ? 1.0 : 0.0));
+        const double e = fabs(val(base + i) - (fg ? 1.0 : 0.0));
         const double m = (fg && ea < e) ? ea : e;
         const double bw = fg ? 1.0 : 2.0 - exp(log(0.5) / 5.0 * sqrt((double)d2[base + i]));
         const double ew = m * bw;
@@ -420,6 +544,28 @@ inline int grid_for(int64_t n, int cap) {
     return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
+// shared tail of the two weighted-F entries: column pass, row pass, weights, partial sums -> out3
+template <typename SRC>
+static int wfm_launch(const SRC& src, const uint8_t* gt, int N, int h, int w, const double* gauss49, int* near_y, int* d2, double* Et,
+                      double* partial, int nparts, double* out3, hipStream_t st) {
+    if (h <= WFM_SEG * WFM_MAXSEG)
+        hipLaunchKernelGGL(wfm_colpass_kernel, dim3((w + 63) / 64, N), dim3(64, 16), 0, st, gt, h, w, near_y);
+    else
+        hipLaunchKernelGGL(wfm_colpass_tall_kernel, dim3((w + 255) / 256, N), dim3(256), 0, st, gt, h, w, near_y);
+    CVLM_CHECK_LAUNCH();
+    const int smem_row = 4 * w * (int)sizeof(int);                   // 128 KB at the widest supported row (w = 8192)
+    if (smem_row > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)wfm_rowpass_kernel<SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_row);
+    hipLaunchKernelGGL(wfm_rowpass_kernel<SRC>, dim3(h, N), dim3(256), smem_row, st, src, gt, h, w, (const int*)near_y, d2, Et);
+    CVLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wfm_weight_kernel<SRC>, dim3(nparts, N), dim3(256), 0, st, src, gt, h, w, (const int*)d2, (const double*)Et, gauss49,
+                       partial);
+    CVLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wfm_finalize_kernel, dim3(N), dim3(256), 0, st, (const double*)partial, nparts, out3);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -463,23 +609,46 @@ int cvlm_mask_wfm(const uint8_t* pre, const uint8_t* gt, int32_t N, int32_t h, i
     int* lohi = (int*)(partial + (size_t)N * nparts * 3);
     hipLaunchKernelGGL(wfm_levels_kernel, dim3(N), dim3(256), 0, st, (const unsigned*)hist, lohi);
     CVLM_CHECK_LAUNCH();
-    if (h <= WFM_SEG * WFM_MAXSEG)
-        hipLaunchKernelGGL(wfm_colpass_kernel, dim3((w + 63) / 64, N), dim3(64, 16), 0, st, gt, h, w, near_y);
-    else
-        hipLaunchKernelGGL(wfm_colpass_tall_kernel, dim3((w + 255) / 256, N), dim3(256), 0, st, gt, h, w, near_y);
+    return wfm_launch(WfmU8{pre, (const int*)lohi}, gt, N, h, w, gauss49, near_y, d2, Et, partial, nparts, out3, st);
+}
+
+// ---- utils.calc_cod on the device (ABI 8): float probability maps, no uint8 step (utils.py:143-165, sod_metric.py:12-26) ---------
+int cvlm_prob_quantise(const float* prob, int32_t N, int32_t h, int32_t w, float* minmax, uint8_t* q, void* workspace, void* stream) {
+    if (!prob || !minmax || !q || !workspace || N <= 0 || h <= 0 || w <= 0) return CVLM_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t hw = (int64_t)h * w;
+    float* partial = (float*)workspace;                              // [N][COD_PARTS][2] at the head of the workspace
+    hipLaunchKernelGGL(cod_minmax_kernel, dim3(COD_PARTS, N), dim3(256), 0, st, prob, hw, partial);
     CVLM_CHECK_LAUNCH();
-    const int smem_row = 4 * w * (int)sizeof(int);                   // 128 KB at the widest supported row (w = 8192)
-    if (smem_row > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)wfm_rowpass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_row);
-    hipLaunchKernelGGL(wfm_rowpass_kernel, dim3(h, N), dim3(256), smem_row, st, pre, gt, h, w, (const int*)near_y,
-                       (const int*)lohi, d2, Et);
-    CVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wfm_weight_kernel, dim3(nparts, N), dim3(256), 0, st, pre, gt, h, w, (const int*)lohi, (const int*)d2,
-                       (const double*)Et, gauss49, partial);
-    CVLM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wfm_finalize_kernel, dim3(N), dim3(256), 0, st, (const double*)partial, nparts, out3);
+    hipLaunchKernelGGL(cod_quant_kernel, dim3(grid_for(hw, 1024), N), dim3(256), 0, st, prob, hw, (const float*)partial, minmax, q);
     CVLM_CHECK_LAUNCH();
     return 0;
+}
+
+int cvlm_prob_moments(const float* prob, const uint8_t* gt, int32_t N, int32_t h, int32_t w, const float* minmax, const uint64_t* stats,
+                      void* workspace, double* out, void* stream) {
+    if (!prob || !gt || !minmax || !stats || !workspace || !out || N <= 0 || h <= 0 || w <= 0) return CVLM_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    double* partial = (double*)workspace;                            // [N][COD_PARTS][16]
+    hipLaunchKernelGGL(cod_moments_kernel, dim3(COD_PARTS, N), dim3(256), 0, st, prob, gt, h, w, minmax,
+                       (const unsigned long long*)stats, partial);
+    CVLM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cod_moments_finalize_kernel, dim3(N), dim3(64), 0, st, (const double*)partial, out);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_prob_wfm(const float* prob, const uint8_t* gt, int32_t N, int32_t h, int32_t w, const float* minmax, const double* gauss49,
+                  void* workspace, double* out3, void* stream) {
+    if (!prob || !gt || !minmax || !gauss49 || !workspace || !out3 || N <= 0 || h <= 0 || w <= 0 || w > 8192 || h > 16384)
+        return CVLM_E_BADARG;
+    const size_t px = (size_t)N * h * w;
+    int* near_y = (int*)workspace;
+    int* d2 = near_y + px;
+    double* Et = (double*)(d2 + px);
+    const int nparts = (int)(((int64_t)h * w + 255) / 256);
+    double* partial = Et + px;
+    return wfm_launch(WfmProb{prob, minmax}, gt, N, h, w, gauss49, near_y, d2, Et, partial, nparts, out3, (hipStream_t)stream);
 }
 
 int cvlm_topk_accumulate(const float* scores, const int32_t* labels, int32_t B, int32_t C, int32_t* pred, uint32_t* counters,

@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 import torch.nn.functional as F
 
-from .evaltail import DeviceClassification, DeviceMetricer
+from .evaltail import DeviceClassification, DeviceCod, DeviceMetricer
 from .preprocess import GpuPreprocess
 
 SECTIONS = ("h2d", "n1_preprocess", "path_infer_test_stage2", "n2_eval_tail")
@@ -42,6 +42,7 @@ class DeviceEvalLoop:
         self.convention = clip_mask_convention
         self.evaluator = DeviceClassification({i: n for i, n in enumerate(self.class_names)}, device=str(self.device))
         self.metricer = DeviceMetricer(self.class_names, metric_names)
+        self.cod = DeviceCod()                                        # utils.calc_cod + its four Averagers (:70-109)
         self.timed = timed
         self.pipelined = pipelined
         self._tail_stream: Optional[torch.cuda.Stream] = None
@@ -84,6 +85,7 @@ class DeviceEvalLoop:
         _, _, pred_1, score = self.model.clip_model(clip_image, alpha, train=False)
         self._mark(marks)
         # N2 (:113-136): top-1 / top-5 counters, then per image sigmoid -> resize to the mask's size -> uint8 -> six metrics
+        self.cod.step(prob, torch.cat([self.pre.mask_input(t) for t in gts]))         # :105 calc_cod(pred_mask, batch['gt'])
         self.evaluator.process(score, labels)
         same = pred_1.to(torch.int64) == labels.to(torch.int64)                        # pre_cls == gt_cls, decided on the device
         masks_u8 = self.metricer.step_batch(pred_mask, gts, same)
@@ -100,6 +102,7 @@ class DeviceEvalLoop:
         tail = self._tail_stream
         tail.wait_event(after)
         with torch.cuda.stream(tail):
+            self.cod.step(torch.sigmoid(masks), torch.cat([self.pre.mask_input(t) for t in gts]))
             self.evaluator.process(logits, labels)
             same = pred.to(torch.int64) == labels.to(torch.int64)
             self.metricer.step_batch(masks, gts, same)
@@ -121,6 +124,11 @@ class DeviceEvalLoop:
             self.events.append(marks)
         self.images += int(inp.shape[0])
         self.last = None
+
+    def cod_results(self) -> Dict[str, float]:
+        """the loop's second metric set: the means of `calc_cod`'s (sm, em, wfm, mae) over all images (val_metric1..4, :72-109);
+        call after `results()`"""
+        return self.cod.result()
 
     def results(self) -> Tuple[Dict[str, float], Dict[str, float]]:
         """-> (`metricer.show(num_bits=None)` dict, `evaluator.evaluate()` dict): the one read-back of the loop."""

@@ -293,6 +293,94 @@ class DeviceMetricer:
         return {k: float(v) for k, v in res.items()}
 
 
+# ---- utils.calc_cod: Sm / Em / wFm / MAE of the float probability map (utils.py:143-165) --------------------------------------------
+def cod_counts(prob: torch.Tensor, gt: torch.Tensor):
+    """prob f32 (N,1,h,w) or (N,h,w) probabilities, gt uint8 (N,h,w) on the GPU -> device tensors (stats int64 (N,3), hist int32
+    (N,4,2,256), moments f64 (N,4,2,2), wfm sums f64 (N,3)): everything `cod_from_counts` needs, 8.3 KB per image."""
+    if prob.dim() == 4:
+        prob = prob[:, 0]
+    prob = prob.float().contiguous()
+    gt = gt.contiguous()
+    n, h, w = prob.shape
+    dev = prob.device
+    ws = torch.empty(hip.prob_workspace_bytes(n, h, w), dtype=torch.uint8, device=dev)
+    minmax = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    q = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+    hip.prob_quantise(prob, minmax, q, ws)
+    stats, hist = mask_counts(q, gt)
+    moments = torch.empty((n, 4, 2, 2), dtype=torch.float64, device=dev)
+    hip.prob_moments(prob, gt, minmax, stats, ws, moments)
+    wsum = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    hip.prob_wfm(prob, gt, minmax, _gauss49(dev), ws, wsum)
+    return stats, hist, moments, wsum
+
+
+def cod_from_counts(stats: np.ndarray, hist: np.ndarray, moments: np.ndarray, wsum: np.ndarray, h: int, w: int) -> Dict[str, float]:
+    """One image of `calc_cod`: sm (Smeasure.cal_sm, alpha 0.5), em (mean of the 256-point E curve), wfm (beta 0.3, the class default),
+    mae -- from the counters and sums of `cod_counts`, in float64 (the reference sums float32 pixels: agreement ~1e-7)."""
+    hist = np.asarray(hist).astype(np.int64).reshape(4, 2, 256)
+    mom = np.asarray(moments, dtype=np.float64).reshape(4, 2, 2)
+    size = h * w
+    total = hist.sum(axis=0)                                          # [class][level] of q = uint8(pn * 255)
+    n1 = int(total[1].sum())
+    n_cell = hist.sum(axis=2).astype(np.float64)                      # [quadrant][class] pixel counts
+    s1, s2 = mom[:, :, 0], mom[:, :, 1]
+    sum_fg, sum_bg = float(s1[:, 1].sum()), float(s1[:, 0].sum())
+    mae = ((n1 - sum_fg) + sum_bg) / size                             # |pn - 1| on the foreground, |pn| on the background
+    tp, fp = np.cumsum(total[1][::-1]), np.cumsum(total[0][::-1])
+    em = float(np.asarray(_em(tp, fp, n1, size), dtype=np.float64).mean())
+    wfm = wfm_from_sums(wsum, beta=0.3)
+    with np.errstate(all="ignore"):
+        mean_all = (sum_fg + sum_bg) / size
+        if n1 == 0:
+            sm = 1 - mean_all
+        elif n1 == size:
+            sm = mean_all
+        else:
+            def s_object(n, a, b, flip):                              # mean / ddof-1 std of pn (or 1 - pn) over one class
+                x = a / n
+                ssd = b - n * x * x
+                x = 1 - x if flip else x
+                return 2 * x / (x ** 2 + 1 + np.sqrt(max(ssd, 0.0) / (n - 1)) + _EPS)
+            u = n1 / size
+            obj = u * s_object(n1, sum_fg, float(s2[:, 1].sum()), False) + (1 - u) * s_object(size - n1, sum_bg, float(s2[:, 0].sum()), True)
+            cnt, sx, sy = (int(v) for v in stats)
+            cx, cy = int(np.round(sx / cnt)) + 1, int(np.round(sy / cnt)) + 1
+            w1, w2, w3 = cx * cy / size, cy * (w - cx) / size, (h - cy) * cx / size
+            reg = 0.0
+            for k, wk in enumerate((w1, w2, w3, 1 - w1 - w2 - w3)):
+                n = n_cell[k].sum()
+                x = s1[k].sum() / n
+                y = n_cell[k][1] / n
+                sxx = (s2[k].sum() - n * x * x) / (n - 1)
+                syy = (n_cell[k][1] * (1 - y) ** 2 + n_cell[k][0] * y ** 2) / (n - 1)
+                sxy = ((s1[k][1] - n_cell[k][1] * x) * (1 - y) + (s1[k][0] - n_cell[k][0] * x) * (0 - y)) / (n - 1)
+                a, b = 4 * x * y * sxy, (x ** 2 + y ** 2) * (sxx + syy)
+                reg = reg + wk * (a / (b + _EPS) if a != 0 else (1 if b == 0 else 0))
+            sm = max(0, 0.5 * obj + 0.5 * reg)
+    return {"sm": float(sm), "em": em, "wfm": float(wfm), "mae": float(mae)}
+
+
+class DeviceCod:
+    """`utils.calc_cod` + the four `utils.Averager`s around it (test_ovcos_maskdecoder_edge.py:70-109): `step` queues the kernels
+    for a batch of probability maps, `result()` reads the counters back once and returns the per-image means (sm, em, wfm, mae)."""
+
+    def __init__(self):
+        self._pending: List[tuple] = []
+
+    def step(self, prob: torch.Tensor, gt: torch.Tensor) -> None:
+        if not prob.is_cuda:
+            raise RuntimeError("DeviceCod.step needs GPU tensors; there is no CPU path")
+        self._pending.append(cod_counts(prob, gt) + (int(prob.shape[-2]), int(prob.shape[-1])))
+
+    def result(self) -> Dict[str, float]:
+        vals = []
+        for stats, hist, mom, wsum, h, w in self._pending:
+            st, hi, mo, wsm = stats.cpu().numpy(), hist.cpu().numpy(), mom.cpu().numpy(), wsum.cpu().numpy()
+            vals += [cod_from_counts(st[i], hi[i], mo[i], wsm[i], h, w) for i in range(st.shape[0])]
+        return {k: float(np.mean([v[k] for v in vals])) for k in ("sm", "em", "wfm", "mae")} if vals else {}
+
+
 class DeviceClassification:
     """`Classification` (recorder/new_evaluator.py:23-100) with the counters kept on the device."""
 

@@ -24,9 +24,9 @@ EXPORTS = [
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
-    "cvlm_ln_stats_merge", "cvlm_small_attention_h2",
+    "cvlm_ln_stats_merge", "cvlm_small_attention_h2", "cvlm_prob_quantise", "cvlm_prob_moments", "cvlm_prob_wfm",
 ]
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class GemmArgs(C.Structure):
@@ -517,3 +517,38 @@ def mask_wfm(pre: torch.Tensor, gt: torch.Tensor, hist: torch.Tensor, gauss49: t
     _check(load().cvlm_mask_wfm(C.c_void_p(pre.data_ptr()), C.c_void_p(gt.data_ptr()), C.c_int32(N), C.c_int32(h), C.c_int32(w),
                                 C.c_void_p(hist.data_ptr()), C.c_void_p(gauss49.data_ptr()), C.c_void_p(workspace.data_ptr()),
                                 C.c_void_p(out3.data_ptr()), C.c_void_p(_stream())), "cvlm_mask_wfm")
+
+
+def prob_workspace_bytes(N: int, h: int, w: int) -> int:
+    """workspace of the three cvlm_prob_* calls (include/cvlm.h, ABI 8)"""
+    return max(mask_wfm_workspace_bytes(N, h, w), N * 8192)
+
+
+def prob_quantise(prob: torch.Tensor, minmax: torch.Tensor, q: torch.Tensor, workspace: torch.Tensor) -> None:
+    """prob f32 [N][h][w] -> minmax f32 [N][2], q uint8 [N][h][w] (utils.calc_cod's `_prepare_data` + the E-measure's levels)."""
+    N, h, w = prob.shape
+    assert prob.dtype == torch.float32 and prob.is_contiguous() and minmax.dtype == torch.float32 and tuple(minmax.shape) == (N, 2)
+    assert q.dtype == torch.uint8 and tuple(q.shape) == (N, h, w) and q.is_contiguous() and workspace.numel() >= prob_workspace_bytes(N, h, w)
+    _check(load().cvlm_prob_quantise(C.c_void_p(prob.data_ptr()), C.c_int32(N), C.c_int32(h), C.c_int32(w), C.c_void_p(minmax.data_ptr()),
+                                     C.c_void_p(q.data_ptr()), C.c_void_p(workspace.data_ptr()), C.c_void_p(_stream())), "cvlm_prob_quantise")
+
+
+def prob_moments(prob: torch.Tensor, gt: torch.Tensor, minmax: torch.Tensor, stats: torch.Tensor, workspace: torch.Tensor,
+                 out: torch.Tensor) -> None:
+    """-> out f64 [N][4][2][2]: (sum pn, sum pn^2) per S-measure quadrant and ground-truth class; stats from mask_joint_hist."""
+    N, h, w = prob.shape
+    assert gt.dtype == torch.uint8 and tuple(gt.shape) == (N, h, w) and gt.is_contiguous() and stats.dtype == torch.int64
+    assert out.dtype == torch.float64 and tuple(out.shape) == (N, 4, 2, 2) and workspace.numel() >= prob_workspace_bytes(N, h, w)
+    _check(load().cvlm_prob_moments(C.c_void_p(prob.data_ptr()), C.c_void_p(gt.data_ptr()), C.c_int32(N), C.c_int32(h), C.c_int32(w),
+                                    C.c_void_p(minmax.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_void_p(workspace.data_ptr()),
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(_stream())), "cvlm_prob_moments")
+
+
+def prob_wfm(prob: torch.Tensor, gt: torch.Tensor, minmax: torch.Tensor, gauss49: torch.Tensor, workspace: torch.Tensor,
+             out3: torch.Tensor) -> None:
+    N, h, w = prob.shape
+    assert out3.dtype == torch.float64 and tuple(out3.shape) == (N, 3) and gauss49.dtype == torch.float64 and gauss49.numel() == 49
+    assert workspace.numel() >= prob_workspace_bytes(N, h, w)
+    _check(load().cvlm_prob_wfm(C.c_void_p(prob.data_ptr()), C.c_void_p(gt.data_ptr()), C.c_int32(N), C.c_int32(h), C.c_int32(w),
+                                C.c_void_p(minmax.data_ptr()), C.c_void_p(gauss49.data_ptr()), C.c_void_p(workspace.data_ptr()),
+                                C.c_void_p(out3.data_ptr()), C.c_void_p(_stream())), "cvlm_prob_wfm")

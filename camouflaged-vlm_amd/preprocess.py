@@ -22,11 +22,29 @@ OPENAI_MEAN, OPENAI_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26
 _PRECISION_BITS = 32 - 8 - 2
 
 
+def nearest_indices(in_size: int, out_size: int) -> np.ndarray:
+    """source index of every output pixel of Pillow's NEAREST resize along one axis (see `_coeffs`)"""
+    scale = np.float64(in_size) / np.float64(out_size)
+    steps = np.full(out_size, scale, dtype=np.float64)
+    steps[0] = scale * 0.5
+    return np.cumsum(steps).astype(np.int64)
+
+
 def _coeffs(in_size: int, out_size: int, filt: str) -> Tuple[np.ndarray, np.ndarray]:
     """Pillow precompute_coeffs + normalize_coeffs_8bpc (libImaging/Resample.c) for every output index at once: the same
     double-precision operations in the same order per row (the window sum runs left to right over the <= ksize taps, one
     vectorised step per tap), so the tables equal the per-index loop bit for bit (tests/test_preprocess.py) -- a new image
     size costs the host ~0.1 ms instead of ~6 ms per table."""
+    if filt == "nearest":
+        # Pillow's NEAREST resize is ImagingScaleAffine (libImaging/Geometry.c): the source coordinate starts at scale / 2 and is
+        # ADVANCED BY REPEATED ADDITION of scale in double (`xo += a[0]`), truncated per output pixel -- not (x + 0.5) * scale, which
+        # lands on the other side of an integer for scales like 3.2.  np.cumsum adds left to right: the same doubles (pinned against
+        # Pillow on 159 size pairs, tests/test_preprocess.py).  As a resample table: one tap of weight 1.0 (2^22: the value comes back
+        # exactly).
+        nearest_index = nearest_indices(in_size, out_size)
+        idx = np.minimum(nearest_index, in_size - 1)
+        return (np.stack([idx, np.ones_like(idx)], axis=1).astype(np.int32),
+                np.full((out_size, 1), 1 << _PRECISION_BITS, dtype=np.int32))
     support0 = 1.0 if filt == "bilinear" else 2.0
     scale = filterscale = float(in_size) / out_size
     filterscale = max(filterscale, 1.0)
@@ -109,6 +127,13 @@ class GpuPreprocess:
         out = torch.empty(r.shape[0], 3, self.S, self.S, device=self.device)
         hip.u8_to_tensor(r, 0, 0, self.S, self.S, self.im_mean, self.im_std, out)
         return out
+
+    def mask_input(self, gt: torch.Tensor) -> torch.Tensor:
+        """datasets/wrappers.py:29-32 `mask_transform` without the float step: Resize((S, S), NEAREST) of a uint8 (h, w) /
+        (N, h, w) ground-truth mask -> uint8 (N, S, S).  (`ToTensor` then divides by 255 and `calc_cod` multiplies it back and
+        thresholds at 128, utils.py:155, sod_metric.py:21: the uint8 levels decide.)"""
+        g = gt.unsqueeze(0) if gt.dim() == 2 else gt
+        return self.resize(g.unsqueeze(-1), self.S, self.S, "nearest")[..., 0]
 
     def clip_input(self, img: torch.Tensor) -> torch.Tensor:
         """Resize(R, BICUBIC) -> CenterCrop(R) -> ToTensor -> Normalize(OpenAI) -> f32 (N,3,R,R)."""

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 7
+#define CVLM_ABI_VERSION 8
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -301,6 +301,21 @@ int cvlm_mask_joint_hist(const uint8_t* pre, const uint8_t* gt, int32_t N, int32
  * ~gt, |gt|): wfm = 2 R P / (R + P) with TPw = |gt| - out[0], P = TPw / (TPw + out[1]), R = 1 - out[0] / |gt|. */
 int cvlm_mask_wfm(const uint8_t* pre, const uint8_t* gt, int32_t N, int32_t h, int32_t w, const uint32_t* hist,
                   const double* gauss49, void* workspace, double* out3, void* stream);
+
+/* ABI 8 -- `utils.calc_cod` (utils.py:143-165): the loop's second metric set, Sm / Em / wFm / MAE of the FLOAT probability map (the
+ * in-tree classes recorder/sod_metric.py:39-581 fed `y_pred * 255` as float32: no uint8 step).  prob f32 [N][h][w] (sigmoid output),
+ * gt u8 [N][h][w] (> 128 = foreground).  Three calls around cvlm_mask_joint_hist, each with the same caller-owned workspace of
+ * max(N*h*w*16 + N*ceil(h*w/256)*24 + N*8, N*8192) bytes:
+ *   cvlm_prob_quantise: minmax f32 [N][2] = min / max of fl(fl(p * 255) / 255) (`_prepare_data`, sod_metric.py:12-26) and
+ *                       q u8 [N][h][w] = uint8(pn * 255), pn = (v - min) / (max - min) in float32 -- the levels the E-measure's
+ *                       cumulative histograms count (:420); then cvlm_mask_joint_hist(q, gt) gives centroid + counters;
+ *   cvlm_prob_moments:  out f64 [N][4 quadrants][2 classes][2] = (sum pn, sum pn^2): S-measure object / region terms and MAE;
+ *   cvlm_prob_wfm:      the weighted F-measure's three sums as cvlm_mask_wfm, E = |pn - gt| from the float map. */
+int cvlm_prob_quantise(const float* prob, int32_t N, int32_t h, int32_t w, float* minmax, uint8_t* q, void* workspace, void* stream);
+int cvlm_prob_moments(const float* prob, const uint8_t* gt, int32_t N, int32_t h, int32_t w, const float* minmax, const uint64_t* stats,
+                      void* workspace, double* out, void* stream);
+int cvlm_prob_wfm(const float* prob, const uint8_t* gt, int32_t N, int32_t h, int32_t w, const float* minmax, const double* gauss49,
+                  void* workspace, double* out3, void* stream);
 
 /* Replaces Classification.process (recorder/new_evaluator.py:47-59): scores f32 [B][C], labels i32 [B] ->
  * pred i32 [B] (may be NULL) and counters u32 [3] += (top-1 hits, top-5 hits, rows).  Counters are NOT zeroed. */

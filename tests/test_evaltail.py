@@ -94,6 +94,51 @@ def test_counts_to_metrics_match_reference_metricer(gold):
                 _close(np.asarray(got[k], dtype=np.float64).reshape(-1), _ref(gold, i, same, k), (i, same, k))
 
 
+def _cod_counts_numpy(p, g):
+    """what cod_counts returns for one image (without the weighted-F sums), built with numpy in the reference's float32 operations"""
+    h, w = g.shape
+    gt = g > 128
+    pred = (p * np.float32(255)) / 255
+    mn, mx = pred.min(), pred.max()
+    pn = (pred - mn) / (mx - mn) if mx != mn else pred
+    q = (pn * 255).astype(np.uint8)
+    stats, hist = _counts_numpy(q, g)
+    cx, cy = M.centroid(gt)
+    yy, xx = np.mgrid[0:h, 0:w]
+    quad = (yy >= cy) * 2 + (xx >= cx)
+    mom = np.zeros((4, 2, 2), dtype=np.float64)
+    for k in range(4):
+        for c in range(2):
+            v = pn[(quad == k) & (gt == bool(c))].astype(np.float64)
+            mom[k, c] = (v.sum(), (v * v).sum())
+    return stats, hist, mom, pn, gt
+
+
+def test_calc_cod_from_counts_matches_reference(gold):
+    """the product's host arithmetic for `utils.calc_cod` (sums per quadrant and class -> Sm, E curve, MAE) against the reference's
+    numbers for the float probability maps of the golden batch (empty and full ground truth included); the weighted F-measure's sums
+    come from the oracle's pixel pass here and from the GPU in test_device_calc_cod_matches_reference"""
+    from scipy.ndimage import convolve, distance_transform_edt as bwdist
+    pred, gtb = gold["cod_pred"], gold["cod_gt"]
+    for k in range(len(pred)):
+        g = (gtb[k, 0] * 255).astype(np.uint8)
+        stats, hist, mom, pn, gt = _cod_counts_numpy(pred[k, 0], g)
+        if gt.any():
+            dst, idx = bwdist(gt == 0, return_indices=True)
+            e = np.abs(pn - gt)
+            et = np.copy(e)
+            et[gt == 0] = et[idx[0][gt == 0], idx[1][gt == 0]]
+            ea = convolve(et, weights=M.gauss2d((7, 7), sigma=5), mode="constant", cval=0)
+            ew = np.where(gt & (ea < e), ea, e) * np.where(gt == 0, 2 - np.exp(np.log(0.5) / 5 * dst), 1.0)
+            wsum = np.asarray([ew[gt].sum(), ew[~gt].sum(), gt.sum()], dtype=np.float64)
+        else:
+            wsum = np.zeros(3)
+        got = E.cod_from_counts(stats, hist, mom, wsum, *g.shape)
+        want = dict(zip(("sm", "em", "wfm", "mae"), gold["cod_per_image"][k]))
+        for key in want:
+            assert abs(got[key] - want[key]) < 2e-6, (k, key, got[key], want[key])
+
+
 def test_oracle_classification_matches_reference_golden(gold):
     pred, c1, c5 = M.classification(gold["cls_scores"], gold["cls_labels"])
     assert [c1, c5, len(pred)] == gold["cls_counts"].tolist()
@@ -268,6 +313,47 @@ def test_device_metricer_end_to_end(gold):
     assert [shown[k] for k in SHOW_KEYS] == gold["show_rounded"].tolist()
     want = M.aggregate(steps)                                  # and the oracle agrees with both
     assert all(abs(float(got[k]) - want[k]) < TOL for k in want)
+
+
+@pytest.mark.gpu
+def test_device_calc_cod_matches_reference(gold):
+    """`utils.calc_cod` on the device (cvlm_prob_quantise / cvlm_prob_moments / cvlm_prob_wfm around cvlm_mask_joint_hist): the batch
+    result and every image alone against the reference's own numbers; the reference sums float32 pixels, the device float64"""
+    pred, gtb = gold["cod_pred"], gold["cod_gt"]
+    g = _dev((gtb[:, 0] * 255).astype(np.uint8))
+    c = E.DeviceCod()
+    c.step(_dev(pred), g)
+    got = c.result()
+    for key, want in zip(("sm", "em", "wfm", "mae"), gold["cod_result"]):
+        assert abs(got[key] - want) < 2e-6, (key, got[key], want)
+    for k in range(len(pred)):
+        c = E.DeviceCod()
+        c.step(_dev(pred[k:k + 1]), g[k:k + 1])
+        one = c.result()
+        for key, want in zip(("sm", "em", "wfm", "mae"), gold["cod_per_image"][k]):
+            assert abs(one[key] - want) < 2e-6, (k, key, one[key], want)
+    # integer parts exactly: the levels and the counters of image 0 equal numpy's
+    stats, hist, mom, _ = (t.cpu().numpy() for t in E.cod_counts(_dev(pred[:1]), g[:1]))
+    ws, wh, wm, _, _ = _cod_counts_numpy(pred[0, 0], (gtb[0, 0] * 255).astype(np.uint8))
+    assert np.array_equal(stats[0], ws) and np.array_equal(hist[0].astype(np.int64), wh)
+    assert np.allclose(mom[0], wm, rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_device_calc_cod_full_size_against_oracle():
+    """1024^2 maps as the loop feeds them (sigmoid of mask logits, NEAREST-resized ground truth): device vs the pinned oracle"""
+    rng = np.random.default_rng(31)
+    h = w = 1024
+    yy, xx = np.mgrid[0:h, 0:w]
+    d = np.sqrt((yy - 430.0) ** 2 + (xx - 600.0) ** 2)
+    prob = (1 / (1 + np.exp(-((250 - d) / 9 + rng.normal(0, 1.0, (h, w)))))).astype(np.float32)[None, None]
+    gt = (d < 240).astype(np.float32)[None, None]
+    want = M.calc_cod(prob, gt)
+    c = E.DeviceCod()
+    c.step(_dev(prob), _dev((gt[:, 0] * 255).astype(np.uint8)))
+    got = c.result()
+    for key, v in zip(("sm", "em", "wfm", "mae"), want):
+        assert abs(got[key] - v) < 5e-6, (key, got[key], v)
 
 
 @pytest.mark.gpu

@@ -99,3 +99,36 @@ def test_gpu_preprocess_bit_exact(gold):
     two = torch.stack([dev, torch.flip(dev, dims=(1,))])
     b2 = pp.sam_input(two)
     assert torch.equal(b2[0], inp[0]) and torch.equal(b2[1], pp.sam_input(torch.flip(dev, dims=(1,)).contiguous())[0])
+
+
+@pytest.mark.gpu
+def test_gpu_nearest_mask_resize_equals_pillow():
+    """datasets/wrappers.py:29-32 `mask_transform`: Resize((S, S), NEAREST) of the uint8 ground truth -- `GpuPreprocess.mask_input`
+    against Pillow itself (and against its index rule, `preprocess.nearest_indices`, when Pillow is not importable)"""
+    from camouflaged_vlm_amd.preprocess import GpuPreprocess, nearest_indices
+    rng = np.random.default_rng(6)
+    pre = GpuPreprocess(320, 56, "cuda")
+    for h, w in ((97, 131), (683, 1024), (320, 320), (7, 5), (1365, 2048), (1024, 683), (600, 800)):
+        a = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        got = pre.mask_input(torch.from_numpy(a).cuda())[0].cpu().numpy()
+        want = a[nearest_indices(h, 320)][:, nearest_indices(w, 320)]
+        try:
+            from PIL import Image
+            assert np.array_equal(want, np.asarray(Image.fromarray(a).resize((320, 320), Image.NEAREST)))
+        except ImportError:
+            pass
+        assert np.array_equal(got, want), (h, w)
+
+
+def test_nearest_index_rule_equals_pillow():
+    """Pillow's NEAREST resize advances the source coordinate by repeated addition (ImagingScaleAffine): `nearest_indices` against
+    Pillow itself on scales where (x + 0.5) * scale would land on the other side of an integer (1024 -> 320 = 3.2, ...)"""
+    Image = pytest.importorskip("PIL.Image")
+    from camouflaged_vlm_amd.preprocess import nearest_indices
+    rng = np.random.default_rng(0)
+    sizes = [(683, 1024, 320, 320), (1365, 2048, 1024, 1024), (1024, 683, 320, 320), (7, 5, 13, 11), (600, 800, 1024, 1024)]
+    sizes += [tuple(int(v) for v in rng.integers(1, 1500, 4)) for _ in range(40)]
+    for h, w, oh, ow in sizes:
+        a = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        want = np.asarray(Image.fromarray(a).resize((ow, oh), Image.NEAREST))
+        assert np.array_equal(a[nearest_indices(h, oh)][:, nearest_indices(w, ow)], want), (h, w, oh, ow)
