@@ -201,7 +201,12 @@ class SamEncoder(_Base):
         self.shared = L(pg + "shared_mlp", k_pad=self.PK)
         self.light = [L(f"{pg}lightweight_mlp_{i}.0", n_pad=self.PK, k_pad=self.PK) for i in range(g.depth)]
         lr, li = lowpass_matrices(g.inp_size, g.fft_halfwidth)
-        self.lstack = H2(H2.pack(torch.cat([lr, li], 0)).t.to(device))       # [2N][N]
+        # [2N][KN]: the contraction length of cvlm_gemm is a multiple of 32, an input size need only be a multiple of the patch (16):
+        # L gets zero columns up to KN = ceil32(N) (336 px -> 352), see `highpass`
+        self.hp_k = _ceil(g.inp_size, 32)
+        lpad = torch.zeros(2 * g.inp_size, self.hp_k)
+        lpad[:, :g.inp_size] = torch.cat([lr, li], 0)
+        self.lstack = H2(H2.pack(lpad).t.to(device))
         # Prompt fold: x_{i+1} = x_i + lin2_i(hid) + shared_mlp(prm_{i+1}) is ONE contraction over K = mlp_dim + PK,
         #   [hid | prm_{i+1}] . [W2_i | W_shared]^T + (b2_i + b_shared) + x_i,
         # so the adapter's per-block `x = prompt_i + x` (image_encoder.py:145) costs 1.25 % more MLP FLOPs instead of
@@ -246,20 +251,24 @@ class SamEncoder(_Base):
     # image_encoder.py:332-353
     def highpass(self, inp: torch.Tensor) -> torch.Tensor:
         B, C, N, _ = inp.shape
-        ws, sp = self.ws, self.prec.gemm
-        xs = ws.h2("hp_x", B * C * N, N)
-        hip.split_f32(inp, xs)
-        pq = ws.h2("hp_pq", B * C * 2 * N, N)                       # per plane: rows [0,N) = P^T, [N,2N) = Q^T
-        hip.gemm(self.lstack, xs, 2 * N, N, N, out_h2=pq, batch=B * C, stride_a=0, stride_w=N * N,
+        ws, sp, KN = self.ws, self.prec.gemm, self.hp_k
+        # KN > N (N not a multiple of 32): the image / P^T / Q^T rows keep their pitch N and the K-tiles of a row run up to 31 elements
+        # into the next row -- finite numbers that meet the zero columns of L.  The last row of a plane runs into the next plane or
+        # into `slack` zero elements behind the buffer (zero-filled when allocated, never written).
+        slack = KN - N
+        xs = ws.h2("hp_x", B * C * N * N + slack, zero=slack > 0)   # flat planes: [B*C*N rows][N] + slack
+        hip.split_f32(inp, xs)                                      # writes numel(inp) elements at the head of each plane
+        pq = ws.h2("hp_pq", B * C * 2 * N * N + slack, zero=slack > 0)       # per problem: rows [0,N) = P^T, [N,2N) = Q^T
+        hip.gemm(self.lstack, xs, 2 * N, N, KN, lda=KN, ldw=N, out_h2=pq, ldoh=N, batch=B * C, stride_a=0, stride_w=N * N,
                  stride_oh=2 * N * N, split=sp)
         t = ws.f32("hp_t", B, C, N, N)
         lr = H2(self.lstack.t[:, :N])
         li = H2(self.lstack.t[:, N:])
-        hip.gemm(lr, pq, N, N, N, residual=inp, out_f32=t, alpha=-1.0, batch=B * C, stride_a=0,
+        hip.gemm(lr, pq, N, N, KN, lda=KN, ldw=N, residual=inp, out_f32=t, alpha=-1.0, batch=B * C, stride_a=0,
                  stride_w=2 * N * N, stride_r=N * N, stride_o=N * N, split=sp)
-        qt = H2(pq.t[:, N:])                                        # Q^T of plane 0; same per-plane stride
+        qt = H2(pq.t[:, N * N:])                                    # Q^T of problem 0; same per-problem stride
         out = ws.f32("hp_out", B, C, N, N)
-        hip.gemm(li, qt, N, N, N, residual=t, out_f32=out, alpha=1.0, act=ACT_ABS_POST, batch=B * C, stride_a=0,
+        hip.gemm(li, qt, N, N, KN, lda=KN, ldw=N, residual=t, out_f32=out, alpha=1.0, act=ACT_ABS_POST, batch=B * C, stride_a=0,
                  stride_w=2 * N * N, stride_r=N * N, stride_o=N * N, split=sp)
         return out
 
