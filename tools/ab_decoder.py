@@ -1,7 +1,7 @@
-"""A/B harness (scratch): the round-3 schedule of the mask decoder (133 launches per forward) as functions that can be patched onto
-engine.MaskDecoder, to time it against the round-4 schedule on one box.  python tools/scratch/ab_decoder.py"""
+"""A/B harness : the round-3 schedule of the mask decoder (133 launches per forward) as functions that can be patched onto
+engine.MaskDecoder, to time it against the round-4 schedule on one box.  python tools/ab_decoder.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from typing import Optional
 from camouflaged_vlm_amd import hip, spec, synth, host
