@@ -78,6 +78,7 @@ def _coeffs(in_size: int, out_size: int, filt: str) -> Tuple[np.ndarray, np.ndar
 
 
 _TABLES: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}      # (n_in, n_out, filter, device) -> device tables, shared by every instance
+_TABLE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
 
 
 def clip_mask_value(convention: str = "wrapper") -> float:
@@ -99,9 +100,16 @@ class GpuPreprocess:
         key = (n_in, n_out, filt, str(self.device))
         if key not in _TABLES:
             b, k = _coeffs(n_in, n_out, filt)
-            # pinned staging: a pageable copy would make the host wait for everything queued on the stream
-            _TABLES[key] = (torch.from_numpy(b).pin_memory().to(self.device, non_blocking=True),
-                            torch.from_numpy(k).pin_memory().to(self.device, non_blocking=True))
+            # The tables are shared by every stream that preprocesses (the evaluation loop's tail stream resizes ground truths):
+            # they are uploaded on a stream of their own, from pinned memory, and the host waits for THAT stream only -- a pageable
+            # copy, or a wait on the caller's stream, would cost the host its lead over everything queued there.
+            st = _TABLE_STREAMS.get(key[3])
+            if st is None:
+                st = _TABLE_STREAMS[key[3]] = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(st):
+                _TABLES[key] = (torch.from_numpy(b).pin_memory().to(self.device, non_blocking=True),
+                                torch.from_numpy(k).pin_memory().to(self.device, non_blocking=True))
+            st.synchronize()
         return _TABLES[key]
 
     def resize(self, img: torch.Tensor, out_h: int, out_w: int, filt: str) -> torch.Tensor:
