@@ -253,16 +253,19 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                     u[tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rh, ql[ks], u[tb], 0, 0, 0);
                 }
             }
-            // the scores use q * scale (image_encoder.py:496), the rel-pos tables q itself (:497-500)
+            // the scores use q * scale (image_encoder.py:496), the rel-pos tables q itself (:497-500).  scale == 1: the caller folded
+            // the factor into the q rows of the qkv projection (and its inverse into the tables): the planes are used as they are
+            if (g.scale != 1.0f) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    half_t hh, ll;
-                    split_h2(((float)qh[ks][j] + (float)ql[ks][j]) * g.scale, hh, ll);
-                    qh[ks][j] = hh;
-                    ql[ks][j] = ll;
-                }
+                    for (int j = 0; j < 8; ++j) {
+                        half_t hh, ll;
+                        split_h2(((float)qh[ks][j] + (float)ql[ks][j]) * g.scale, hh, ll);
+                        qh[ks][j] = hh;
+                        ql[ks][j] = ll;
+                    }
+            }
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 int cq = tb ? qww : qhh;

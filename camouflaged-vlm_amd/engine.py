@@ -223,22 +223,35 @@ class SamEncoder(_Base):
         self.ln_fold = os.environ.get("CVLM_LN_FOLD", "1") == "1"
         self.fold_disabled = False          # set by Cascade's refusal guard: rows with |mu|/sigma > 128 met -> separate LayerNorm passes
         self.blocks = []
+        # The attention's `(q * scale) k^T` (image_encoder.py:496) with the factor folded into the q rows of the qkv projection
+        # (weight and bias; the pad tokens' q = bias row follows), and its inverse into the rel-pos tables, which the reference applies
+        # to the UNSCALED q (:497-500): q' . (R / scale) = q . R.  The kernels are then called with scale = 1 and use the projected
+        # planes as they are -- re-splitting 80 values per query per (window, head) pair was 5 % of the window kernel (262 -> 251 us,
+        # tools/bench_attn.py SCALE=1).  Same mathematics, rounding points 2^-22 apart.
+        qs = float(g.head_dim) ** -0.5
+
+        def scaled_qkv(i):
+            w = sd[P + f"blocks.{i}.attn.qkv.weight"].detach().float().cpu().clone()
+            bq = sd[P + f"blocks.{i}.attn.qkv.bias"].detach().float().cpu().clone()
+            w[:D] *= qs
+            bq[:D] *= qs
+            return w, bq
         for i in range(g.depth):
             b = f"blocks.{i}."
+            qkv_w, qkv_b = scaled_qkv(i)
             blk = dict(
                 n1w=self.dev(sd[P + b + "norm1.weight"]), n1b=self.dev(sd[P + b + "norm1.bias"]),
                 n2w=self.dev(sd[P + b + "norm2.weight"]), n2b=self.dev(sd[P + b + "norm2.bias"]),
                 # with the fold on, qkv / lin1 (and lin2 of every block but the last: lin2cat carries it) are launched by the tap
                 # schedule and the refusal fallback only: planar, no 128-byte-row image (~1 GB at ViT-H)
-                qkv=L(b + "attn.qkv", il=not self.ln_fold), proj=L(b + "attn.proj"), lin1=L(b + "mlp.lin1", il=not self.ln_fold),
+                qkv=Linear(qkv_w, qkv_b, device, il=not self.ln_fold), proj=L(b + "attn.proj"), lin1=L(b + "mlp.lin1", il=not self.ln_fold),
                 lin2=L(b + "mlp.lin2", il=not self.ln_fold or i == g.depth - 1),
-                pad=H2(H2.pack(sd[P + b + "attn.qkv.bias"].detach().float().cpu()).t.to(device)),
-                rel_h=H2(H2.pack(sd[P + b + "attn.rel_pos_h"].detach().float().cpu()).t.to(device)),
-                rel_w=H2(H2.pack(sd[P + b + "attn.rel_pos_w"].detach().float().cpu()).t.to(device)),
+                pad=H2(H2.pack(qkv_b).t.to(device)),
+                rel_h=H2(H2.pack(sd[P + b + "attn.rel_pos_h"].detach().float().cpu() / qs).t.to(device)),
+                rel_w=H2(H2.pack(sd[P + b + "attn.rel_pos_w"].detach().float().cpu() / qs).t.to(device)),
                 window=0 if i in g.global_attn_indexes else g.window_size)
             if self.ln_fold:
-                blk["qkv_f"] = LnLinear(sd[P + b + "attn.qkv.weight"], sd[P + b + "attn.qkv.bias"],
-                                        sd[P + b + "norm1.weight"], sd[P + b + "norm1.bias"], device)
+                blk["qkv_f"] = LnLinear(qkv_w, qkv_b, sd[P + b + "norm1.weight"], sd[P + b + "norm1.bias"], device)
                 blk["lin1_f"] = LnLinear(sd[P + b + "mlp.lin1.weight"], sd[P + b + "mlp.lin1.bias"],
                                          sd[P + b + "norm2.weight"], sd[P + b + "norm2.bias"], device)
             self.blocks.append(blk)
@@ -348,10 +361,10 @@ class SamEncoder(_Base):
             if blk["window"] > 0:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
                                pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
-                               head_major=True)
+                               head_major=True, scale=1.0)
             else:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
-                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
+                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True, scale=1.0)
             self.gemm(att, blk["proj"], M, residual=x, out_f32=x)
             hip.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, M, D, out_h2=xn)
             self.gemm(xn, blk["lin1"], M, out_h2=hid, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE)
@@ -403,10 +416,10 @@ class SamEncoder(_Base):
             if blk["window"] > 0:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
                                pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
-                               head_major=True)
+                               head_major=True, scale=1.0)
             else:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
-                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True)
+                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True, scale=1.0)
             self.gemm(att, blk["proj"], M, out_h2=xo, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=pcs)
             xh = xo                                                  # from here on the stream is read where it was written
             hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)

@@ -6,6 +6,7 @@ from camouflaged_vlm_amd import hip
 hip.load()
 split = (3, 3) if len(sys.argv) < 2 else tuple(int(c) for c in sys.argv[1])
 hm = os.environ.get("HM", "1") == "1"
+SCALE = float(os.environ["SCALE"]) if "SCALE" in os.environ else None      # SCALE=1: the factor folded into the projection (kernels skip the re-split)
 def run(name, fn, flops, n=5):
     for _ in range(2): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -23,7 +24,7 @@ rw = hip.H2((torch.randn(2, 27, hd, device="cuda") * 0.1).half())
 pad = hip.H2((torch.randn(2, 3 * D, device="cuda") * 0.1).half())
 run("sam global", lambda: hip.attention(qkv, out, B, S, H, hd, mode=1, grid=G, rel_h=rg, rel_w=rg, split_qk=split[0], split_pv=split[1], head_major=hm),
     4.0 * B * H * S * S * hd)
-run("sam window", lambda: hip.attention(qkv, out, B, S, H, hd, mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw, split_qk=split[0], split_pv=split[1], head_major=hm),
+run("sam window", lambda: hip.attention(qkv, out, B, S, H, hd, mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw, split_qk=split[0], split_pv=split[1], head_major=hm, scale=SCALE),
     4.0 * B * H * 25 * 196 * 196 * hd)
 Hc, hc, Sc = 16, 64, 581
 q2 = hip.H2(torch.randn(2, B * Sc, 3 * Hc * hc, device="cuda").half())
