@@ -652,7 +652,7 @@ def main():
     # never a finiteness check alone.  Geometries without a digest (tiny) keep disjoint image ranges per rank.
     n_dig = {"demo": 16, "hires1536": 4}.get(args.geometry)
     if n_dig:
-        ids = [[(rank + k * B + i) % n_dig for i in range(B)] for k in range(2)]
+        ids = digest.rank_batches(rank, B, n_dig)
     else:
         ids = [list(range((2 * rank + k) * B, (2 * rank + k + 1) * B)) for k in range(2)]
 

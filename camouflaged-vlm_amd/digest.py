@@ -95,3 +95,10 @@ def check_demo_features(feats, grid: int, dg, image_ids: Sequence[int]) -> dict:
 
 def check_hires_features(feats, grid: int, dg, image_ids: Sequence[int]) -> dict:
     return check_features(feats, grid, dg, image_ids, "samples", "sample_idx", "channel_mean")
+
+
+def rank_batches(rank: int, batch: int, n_digest: int, n_batches: int = 2):
+    """Image ids of the batches rank `rank` alternates in bench.py's timed loop: the digest's images rotated by the rank, batch k =
+    {(rank + k * batch + i) mod n_digest}.  Every id is a digest image, so every rank's parity check is a check against the reference
+    (SURVEY.md section 4(iv)); ranks differ in order and, for batch < n_digest, in content."""
+    return [[(rank + k * batch + i) % n_digest for i in range(batch)] for k in range(n_batches)]

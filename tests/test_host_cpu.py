@@ -483,3 +483,30 @@ def test_launcher_forgets_reference_modules_imported_earlier(tmp_path):
         for k in [k for k in sys.modules if k.split(".")[0] in run.SHADOWED]:
             del sys.modules[k]
         sys.modules.update(saved_mods)
+
+
+def test_every_rank_draws_its_batches_from_the_reference_digest():
+    """bench.py --gpus N (BASELINE configs[3]): whatever the rank and the batch size, every image of the timed batches is one the
+    reference digest holds -- no rank passes its parity check on finiteness alone"""
+    from camouflaged_vlm_amd import digest
+    for world in (1, 2, 4, 8):
+        seen = set()
+        for rank in range(world):
+            for B, n in ((8, 16), (4, 4), (1, 16), (3, 16)):
+                ids = digest.rank_batches(rank, B, n)
+                assert len(ids) == 2 and all(len(b) == B and all(0 <= i < n for i in b) for b in ids)
+                if (B, n) == (8, 16):
+                    assert sorted(ids[0] + ids[1]) == list(range(16))          # the two batches of a rank cover the whole digest
+                    seen.add(tuple(ids[0]))
+        assert len(seen) == world                                                # and the ranks' batches are different rotations
+    class FakeT:                                                                 # check_* skip ids the digest lacks and say so: ok is None
+        def __init__(self, a): self.a = a
+        def detach(self): return self
+        def float(self): return self
+        def cpu(self): return self
+        def numpy(self): return self.a
+    import numpy as np
+    dg = {"pred": np.zeros(2, np.int64), "mask_bits": np.zeros((2, 1), np.uint8), "sample_idx": np.zeros(1, np.int64),
+          "mask_samples": np.zeros((2, 1), np.float32), "class_logits": np.zeros((2, 3), np.float32)}
+    r = digest.check_cascade(FakeT(np.zeros((1, 1, 2, 2), np.float32)), FakeT(np.zeros(1, np.int64)), FakeT(np.zeros((1, 3), np.float32)), dg, [5])
+    assert r == {"checked_images": [], "ok": None}
