@@ -431,8 +431,9 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
     n_items = max(16, 2 * B)
     data = synthetic_dataset(np, n_items, len(names))
     pin = lambda a: torch.from_numpy(a).pin_memory()
-    items = [(pin(im), pin(gt), lab) for im, gt, lab in data]
     nb = n_items // B
+    data = data[:nb * B]                                  # whole batches only (a batch size that does not divide the split drops the rest)
+    items = [(pin(im), pin(gt), lab) for im, gt, lab in data]
 
     def batch(k):
         sel = items[(k % nb) * B:(k % nb + 1) * B]
