@@ -37,3 +37,15 @@ stats = torch.empty(B, 3, dtype=torch.int64, device="cuda"); hist = torch.empty(
 run("N2 centroid + joint histograms 768x1024 (noise)", lambda: hip.mask_joint_hist(u8, gt, stats, hist), B * 768 * 1024 * 3)
 spike = torch.where(torch.rand(B, 768, 1024, device="cuda") < 0.9, 0, 255).to(torch.uint8)
 run("N2 centroid + joint histograms (two-spike mask)", lambda: hip.mask_joint_hist(spike, gt, stats, hist), B * 768 * 1024 * 3)
+# ---- N2, round 4: the weighted F-measure (blob ground truth, as camouflage masks are) and utils.calc_cod on float maps
+yy, xx = torch.meshgrid(torch.arange(768, device="cuda"), torch.arange(1024, device="cuda"), indexing="ij")
+blob = (((yy - 380) ** 2 + (xx - 520) ** 2) < 200 ** 2).to(torch.uint8) * 255
+gtb = blob[None].repeat(B, 1, 1).contiguous()
+pre = torch.clamp(gtb.float() * 0.8 + torch.randn(B, 768, 1024, device="cuda") * 25 + 30, 0, 255).to(torch.uint8)
+hip.mask_joint_hist(pre, gtb, stats, hist)
+# bytes the pass has to move at least: gt + pre read, near_y / d2 (4 B) + Et (8 B) written and read once
+run("N2 weighted F-measure sums 768x1024 (uint8 mask)", lambda: evaltail.mask_wfm_sums(pre, gtb, hist), B * 768 * 1024 * (2 + 2 * 16))
+prob = torch.sigmoid(torch.randn(B, 1024, 1024, device="cuda") * 3)
+gts = (torch.rand(B, 1024, 1024, device="cuda") < 0.0).to(torch.uint8)
+gts[:, 300:700, 250:800] = 255
+run("N2 calc_cod counters 1024^2 (float map)", lambda: evaltail.cod_counts(prob, gts), B * 1024 * 1024 * (4 * 4 + 2 + 2 * 16))
