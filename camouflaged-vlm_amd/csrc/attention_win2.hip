@@ -60,6 +60,16 @@ constexpr OneHotImage2 make_onehot_image2() {
 }
 __device__ const OneHotImage2 g_onehot2 = make_onehot_image2();
 
+#ifdef CVLM_PROBES
+// probe builds (tools/trace_attn_win2.py): per workgroup and consumer wave, the time in the three stages of a pair, summed over its pairs:
+// [U = Q.R^T + scatter | seven key tiles | output | pairs | first stamp | last stamp | of the tiles: waiting at the step barriers | HW_ID],
+// 100-MHz wall-clock ticks
+__device__ unsigned long long* g_win2_trace = nullptr;
+#define WIN2_STAMP(x) do { if (trace) { __builtin_amdgcn_sched_barrier(0); x = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define WIN2_STAMP(x) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_args g, const int nwx, const int npairs) {
     constexpr int HD = 80, KS = 5, NDB = 5, CPR = 10, KP = 80, VP = 80, L = 14, S_SEQ = 196;
     constexpr int KT = 32, NKT = 7, NCW = 7;                        // 7 key tiles, 7 consumer waves
@@ -222,6 +232,10 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
         }
     };
     if (my_items > 0) load_q(pair_of(0));
+#ifdef CVLM_PROBES
+    unsigned long long* const trace = g_win2_trace;
+    unsigned long long ta = 0, tb = 0, tc = 0, td = 0, acc_u = 0, acc_t = 0, acc_o = 0, acc_bar = 0, t_first = 0;
+#endif
 
 #pragma unroll 1
     for (int k = 0; k < my_items; ++k) {
@@ -232,6 +246,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { qh[ks] = qn_h[ks]; ql[ks] = qn_l[ks]; }
         if (first) { step_barrier(); first = false; }                // B_start (once): tables and one-hot block are in LDS
+        WIN2_STAMP(ta);
         // ---- Th / Tw for this query: U = Q . R^T (27 rows -> one 32-row MFMA tile per table), scattered through Taug
         {
             const int qhh = qs / L, qww = qs - qhh * L;
@@ -289,6 +304,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
             }
         }
 
+        WIN2_STAMP(tb);
         float m_run = -INFINITY, l_run = 0.f;
         // O^T as 16 x 16 tiles of the 16x16x32 MFMA (as in attention_g64pp.hip): [16-dim block][query block], this lane holds dims
         // 16 db + 4 (lane >> 4) + j of query 16 qb + (lane & 15): head_dim 80 = 5 blocks, no padding to 96 (15 instead of 18
@@ -335,7 +351,15 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 
         auto tile = [&](int t, auto has_next_c, auto next_last_c) {
             constexpr bool HAS_NEXT = decltype(has_next_c)::value;
+#ifdef CVLM_PROBES
+            unsigned long long te = 0, tf = 0;
+            WIN2_STAMP(te);
+#endif
             step_barrier();                                           // B_(gt0 + t): K(gt0 + t + 1) and V(gt0 + t) have landed
+#ifdef CVLM_PROBES
+            WIN2_STAMP(tf);
+            if (trace) acc_bar += tf - te;
+#endif
 #if defined(CVLM_WIN2_PROBE) && CVLM_WIN2_PROBE == 1
             return;                                                   // probe: consumers only keep step with the producer
 #endif
@@ -419,6 +443,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
         tile(NKT - 2, yes_c{}, yes_c{});
         if (k + 1 < my_items) load_q(pair_of(k + 1));
         tile(NKT - 1, no_c{}, no_c{});
+        WIN2_STAMP(tc);
 
         // ---- output.  A lane holds dims 16 db + 4 g .. + 3 of queries (lane & 15) + 16 qb; one v_permlane16_swap per register
         // pair hands a neighbouring 4-dim piece across (even g: the next four dims of block db from lane + 16; odd g: the four
@@ -465,11 +490,26 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                 if (ok2) *(u32x2*)(dst + 64 + 4 * g4) = u32x2{ph2[4][pl][0], ph2[4][pl][1]};
             }
         }
+#ifdef CVLM_PROBES
+        WIN2_STAMP(td);
+        if (trace) { acc_u += tb - ta; acc_t += tc - tb; acc_o += td - tc; if (k == 0) t_first = ta; }
+#endif
     }
+#ifdef CVLM_PROBES
+    if (trace && lane == 0) {
+        unsigned long long* o = trace + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = acc_u; o[1] = acc_t; o[2] = acc_o; o[3] = (unsigned long long)my_items; o[4] = t_first; o[5] = td; o[6] = acc_bar;
+        o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                 // HW_ID: SIMD in bits 5:4
+    }
+#endif
     if (first) step_barrier();                                        // a workgroup without pairs still meets the producer at B_start
 }
 
 }  // namespace
+
+#ifdef CVLM_PROBES
+extern "C" int cvlm_debug_set_attn_win2_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_win2_trace), &buf, sizeof(buf)); }
+#endif
 
 // exact-mode (split 3/3) producer / consumer form; called from cvlm_attention_window14() when selected
 int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s) {
