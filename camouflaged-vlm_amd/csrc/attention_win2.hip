@@ -381,9 +381,24 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 #pragma unroll
             for (int r = 2; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
             mx = half_swap_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-            const f32x2 c2 = f32x2{-m_new * LOG2E, -m_new * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
+            // The reference point of the exponentials moves only when some query of the wave finds a score more than TAU above its
+            // own: until then P = exp(s - m_run) may exceed 1 (by at most e^TAU = 148, nothing to an fp16 hi / lo pair or to the f32
+            // sums) and the 40 accumulator values, the running sum and their factor need no touching -- 24 VALU instructions of a
+            // tile's ~150, and on this part VALU instructions are not hidden behind the MFMAs: a SIMD runs the one or the other
+            // (profiles/r04_mfma_valu_overlap.log).  Same quotient O / l; the rounding points move by the common factor.
+            constexpr float TAU = 5.0f;
+            if (__builtin_amdgcn_ballot_w64(mx > m_run + TAU) != 0) {     // wave-uniform; the first tile of a pair always (m_run = -inf)
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+                l_run *= alpha;
+                // the O^T tiles hold queries (lane & 15) + 16 qb: this lane's own factor serves one block, the lane 16 away holds the other
+                const auto ax = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, alpha), __builtin_bit_cast(unsigned, alpha), false, false);
+                const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
+#pragma unroll
+                for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
+                m_run = m_new;
+            }
+            const f32x2 c2 = f32x2{-m_run * LOG2E, -m_run * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
             f32x2 z[8], acc = f32x2{0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -391,14 +406,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                 z[i] = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
                 acc += z[i];
             }
-            l_run = l_run * alpha + (acc.x + acc.y);
-            {   // the O^T tiles hold queries (lane & 15) + 16 qb: this lane's own factor serves one block, the lane 16 away holds the other
-                const auto ax = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, alpha), __builtin_bit_cast(unsigned, alpha), false, false);
-                const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
-#pragma unroll
-                for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
-            }
-            m_run = m_new;
+            l_run += acc.x + acc.y;
             // P (hi truncated by cvt_pkrtz, lo = e - hi: exact remainder): first / last eight values of the lane, register by register
             // through v_permlane16_swap -> the B operands of query blocks 0 and 1
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
