@@ -352,7 +352,8 @@ int launch(const AttnParams& p, hipStream_t s) {
     if (smem > 48 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const int nseq = (MODE == 2) ? p.a.B * p.nwx * p.nwx : p.a.B;
-    dim3 grid((p.S_seq + NW * 32 - 1) / (NW * 32), p.a.heads, nseq), block(NW * 64);
+    const int q_rows = (MODE == 0 && p.a.q_rows > 0 && p.a.q_rows < p.S_seq) ? p.a.q_rows : p.S_seq;   // ABI 9: leading query blocks only
+    dim3 grid((q_rows + NW * 32 - 1) / (NW * 32), p.a.heads, nseq), block(NW * 64);
     hipLaunchKernelGGL(kern, grid, block, smem, s, p);
     CVLM_CHECK_LAUNCH();
     return 0;
@@ -382,7 +383,7 @@ extern "C" int64_t cvlm_attention_workspace_bytes(const cvlm_attn_args* args) {
 extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!args || !args->qkv_hi || !args->out_hi) return CVLM_E_BADARG;
     const cvlm_attn_args& g = *args;
-    if (g.B <= 0 || g.S <= 0 || g.heads <= 0) return CVLM_E_BADARG;
+    if (g.B <= 0 || g.S <= 0 || g.heads <= 0 || g.q_rows < 0 || (g.q_rows > 0 && g.mode != 0)) return CVLM_E_BADARG;
     if ((g.split_qk == 3 || g.split_pv == 3) && !g.qkv_lo) return CVLM_E_BADARG;
     AttnParams p;
     p.a = g;

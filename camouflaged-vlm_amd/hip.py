@@ -26,7 +26,7 @@ EXPORTS = [
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
     "cvlm_ln_stats_merge", "cvlm_small_attention_h2", "cvlm_prob_quantise", "cvlm_prob_moments", "cvlm_prob_wfm",
 ]
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class GemmArgs(C.Structure):
@@ -59,7 +59,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("S", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
         ("mode", C.c_int32), ("grid", C.c_int32), ("window", C.c_int32), ("causal", C.c_int32),
         ("split_qk", C.c_int32), ("split_pv", C.c_int32), ("scale", C.c_float), ("qkv_layout", C.c_int32),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("q_rows", C.c_int32),
     ]
 
 
@@ -351,8 +351,9 @@ def reinterpret_transpose(x: torch.Tensor, B: int, T: int, D: int, out: H2, scal
 def attention(qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, *, mode: int = 0, grid: int = 0, window: int = 0,
               causal: bool = False, pad: Optional[H2] = None, rel_h: Optional[H2] = None, rel_w: Optional[H2] = None,
               split_qk: int = 3, split_pv: int = 3, scale: Optional[float] = None, head_major: bool = False,
-              workspace: Optional[torch.Tensor] = None) -> None:
-    """workspace: uint8 tensor of >= attention_workspace_bytes(...) bytes for the modes that need one; when omitted a
+              workspace: Optional[torch.Tensor] = None, q_rows: int = 0) -> None:
+    """q_rows > 0 (mode 0, ABI 9): only the first q_rows queries of every sequence (whole 128-query blocks are written).
+    workspace: uint8 tensor of >= attention_workspace_bytes(...) bytes for the modes that need one; when omitted a
     temporary is taken from torch's allocator (stream-ordered, so it may be released right after the launch)."""
     _on_current_device(qkv.t)
     a = AttnArgs()
@@ -368,6 +369,7 @@ def attention(qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, *, mode: in
     a.split_qk, a.split_pv = split_qk, split_pv
     a.scale = float(hd) ** -0.5 if scale is None else scale
     a.qkv_layout = int(head_major)
+    a.q_rows = q_rows
     need = int(load().cvlm_attention_workspace_bytes(C.byref(a)))
     if need > 0:
         if workspace is None or workspace.numel() * workspace.element_size() < need:

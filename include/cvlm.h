@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 8
+#define CVLM_ABI_VERSION 9
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -203,6 +203,11 @@ typedef struct cvlm_attn_args {
     int32_t qkv_layout;          /* 0: token-major [B*S][3][H][hd]; 1: head-major [3][B][H][S][hd] */
     void* workspace;             /* ABI 2 */
     int64_t workspace_bytes;     /* ABI 2 */
+    /* ABI 9 -- mode 0 only: q_rows > 0 computes the attention output of the FIRST q_rows queries of every sequence only (whole
+     * 128-query blocks: rows up to the end of the last block touched are written, the rest of `out` is left alone); keys and values
+     * are all S rows as ever.  The last block of the CLIP vision tower feeds nothing but its class token (row 0) into ln_post
+     * (alpha_clip_rw/model.py:558-561): its attention is called with q_rows = 1.  0 = every query. */
+    int32_t q_rows;
 } cvlm_attn_args;
 int cvlm_attention(const cvlm_attn_args* args, void* stream);
 int64_t cvlm_attention_workspace_bytes(const cvlm_attn_args* args);
