@@ -246,8 +246,26 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                 int kh0 = 0, kw0 = 0;
                 if (MODE != 0) { kh0 = b0 / L; kw0 = b0 - kh0 * L; }
                 float mx = -INFINITY;
+                // MODE 0 (the CLIP towers): nothing is added to the scores, so they stay UNSCALED in the registers -- the factor rides
+                // on the exponent's multiplier below and on the one maximum -- and slots are masked only where a mask can bite (the last
+                // key tile; the causal text tower): 16 multiplies and 32 compare / select instructions less per 32 keys in a kernel
+                // whose vector instructions are not hidden behind its MFMAs (profiles/r04_mfma_valu_overlap.log)
+                if (MODE == 0) {
+                    if (CAUSAL || t * 64 + sub * 32 + 32 > S_seq) {       // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int slot = b0 + (r & 3) + 8 * (r >> 2);
+                            const bool ok = (slot < S_seq) && (!CAUSAL || slot <= qslot);
+                            s[r] = ok ? s[r] : -INFINITY;
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                    mx *= scale;                                          // scale > 0
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+                    if (MODE == 0) break;
                     const int c = (r & 3) + 8 * (r >> 2);
                     const int slot = b0 + c;
                     float v = s[r] * scale;
@@ -265,9 +283,21 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                     mx = fmaxf(mx, v);
                 }
                 mx = half_swap_max(mx);
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-                const f32x2 c2 = f32x2{-m_new * LOG2E, -m_new * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
+                // the reference point of the exponentials moves only when some query of the wave meets a score more than TAU above its
+                // own (attention_win2.hip): otherwise accumulators, sum and factor are left alone
+                constexpr float TAU = 5.0f;
+                if (__builtin_amdgcn_ballot_w64(mx > m_run + TAU) != 0) {   // wave-uniform; always on the first tile (m_run = -inf)
+                    const float m_new = fmaxf(m_run, mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+                    l_run *= alpha;
+#pragma unroll
+                    for (int n = 0; n < ND; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+                    m_run = m_new;
+                }
+                const float lscale = MODE == 0 ? scale * LOG2E : LOG2E;
+                const f32x2 c2 = f32x2{-m_run * LOG2E, -m_run * LOG2E}, l2 = f32x2{lscale, lscale};
                 f32x2 z[8], acc = f32x2{0.f, 0.f};                   // packed fp32: half the VALU instructions
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -275,14 +305,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const AttnParams p) {
                     z[i] = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
                     acc += z[i];
                 }
-                l_run = l_run * alpha + (acc.x + acc.y);
-                if (!__all(m_new == m_run)) {
-#pragma unroll
-                    for (int n = 0; n < ND; ++n)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
-                }
-                m_run = m_new;
+                l_run += acc.x + acc.y;
                 // ---- O^T += V^T . P^T   (k-order of each 16-slot step = accumulator register order)
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
