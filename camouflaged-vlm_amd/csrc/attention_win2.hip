@@ -293,12 +293,17 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                     Tq[ok ? kidx : 16] = u[tb][r];
                 }
                 __builtin_amdgcn_wave_barrier();                      // rows are wave-private: LDS keeps a wave's accesses in order
+                {
+                    typedef unsigned u32x4_s __attribute__((ext_vector_type(4)));
+                    u32x4_s h4, l4;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    half_t h, l;
-                    split_h2(Tq[8 * half + j], h, l);
-                    qh[KS + tb][j] = h;
-                    ql[KS + tb][j] = l;
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned a, b;
+                        split_h2_pk(Tq[8 * half + 2 * j], Tq[8 * half + 2 * j + 1], a, b);
+                        h4[j] = a; l4[j] = b;
+                    }
+                    qh[KS + tb] = __builtin_bit_cast(half8, h4);
+                    ql[KS + tb] = __builtin_bit_cast(half8, l4);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -472,13 +477,8 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
             unsigned ph2[NDB][2][2];                                  // [block][plane][dword]: this lane's 4 dims as packed halves
 #pragma unroll
             for (int n = 0; n < NDB; ++n) {
-                half_t h[4], l4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) split_h2(o[n][qb][j] * invq[qb], h[j], l4[j]);
-                ph2[n][0][0] = __builtin_bit_cast(unsigned, half2v{h[0], h[1]});
-                ph2[n][0][1] = __builtin_bit_cast(unsigned, half2v{h[2], h[3]});
-                ph2[n][1][0] = __builtin_bit_cast(unsigned, half2v{l4[0], l4[1]});
-                ph2[n][1][1] = __builtin_bit_cast(unsigned, half2v{l4[2], l4[3]});
+                split_h2_pk(o[n][qb][0] * invq[qb], o[n][qb][1] * invq[qb], ph2[n][0][0], ph2[n][1][0]);
+                split_h2_pk(o[n][qb][2] * invq[qb], o[n][qb][3] * invq[qb], ph2[n][0][1], ph2[n][1][1]);
             }
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {

@@ -51,6 +51,17 @@ __device__ __forceinline__ unsigned split_lo_pk(unsigned h, float vx, float vy) 
     return lo;
 }
 
+// split_h2 of two values at once, three instructions instead of eight: hi = v_cvt_pk_f16_f32 (round to nearest, both values), lo =
+// fp16(v - hi) by split_lo_pk -- the bits of split_h2 (the difference is exact in f32 either way and is rounded once).  Vector
+// instructions are not hidden behind MFMAs on this part (profiles/r04_mfma_valu_overlap.log): every GEMM tile's epilogue splits 128
+// values per lane.  hi / lo: the two fp16 values packed as they are stored ([31:16] = second value).
+__device__ __forceinline__ void split_h2_pk(float vx, float vy, unsigned& hi, unsigned& lo) {
+    asm volatile("" : "+v"(vx), "+v"(vy));                               // pin the rounded f32 values first: see split_h2
+    typedef float f32x2_cvt __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_cvt{vx, vy}, half2v));
+    lo = split_lo_pk(hi, vx, vy);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

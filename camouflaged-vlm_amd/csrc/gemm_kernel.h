@@ -883,15 +883,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                                 asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
                                 continue;
                             }
-                            half8 hi, lo;
+                            typedef unsigned u32x4_s __attribute__((ext_vector_type(4)));
+                            u32x4_s hi4, lo4;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                float u = v[j] * oscale;
-                                if (ACT == ACT_ABS_POST) u = fabsf(u);
-                                half_t a, b2;
-                                split_h2(u, a, b2);
-                                hi[j] = a; lo[j] = b2;
+                            for (int j = 0; j < 4; ++j) {
+                                float u0 = v[2 * j] * oscale, u1 = v[2 * j + 1] * oscale;
+                                if (ACT == ACT_ABS_POST) { u0 = fabsf(u0); u1 = fabsf(u1); }
+                                unsigned a, b2;
+                                split_h2_pk(u0, u1, a, b2);
+                                hi4[j] = a; lo4[j] = b2;
                             }
+                            const half8 hi = __builtin_bit_cast(half8, hi4), lo = __builtin_bit_cast(half8, lo4);
                             int64_t off = (int64_t)m * g.ldoh + (g.out_il ? ((nh >> 5) << 6) + (nh & 31) : nh);   // out_il: [m][n / 32][plane][32]
                             if (g.hm_S > 0) {                              // row part: rows advance by mt * 16 + 8 * i < hm_S
                                 int tk = hm_t + mt * 16 + 8 * i, bi = hm_b;
