@@ -652,6 +652,27 @@ def test_attention_plain(hip, S, causal, split):
     assert relerr(out.float(), ref) < tol
 
 
+@pytest.mark.parametrize("S,q_rows", [(581, 1), (581, 130), (77, 1), (581, 600)])
+def test_attention_leading_queries_only(hip, S, q_rows):
+    """cvlm_attn_args.q_rows (ABI 9): only the leading query blocks are computed -- the bits of the whole launch in the rows of the
+    blocks touched, nothing written behind them (the class-token tail of the CLIP tower asks for q_rows = 1)."""
+    Bn, Hh, hd = 3, 4, 64
+    D = Hh * hd
+    Q = dev_h2(hip, rnd(Bn * S, 3 * D, seed=23))
+    full, part = hip.H2.empty(Bn * S, D), hip.H2.empty(Bn * S, D)
+    full.t.fill_(float("nan"))
+    part.t.fill_(7.0)
+    hip.attention(Q, full, Bn, S, Hh, hd, mode=0)
+    hip.attention(Q, part, Bn, S, Hh, hd, mode=0, q_rows=q_rows)
+    torch.cuda.synchronize()
+    rows = min(S, -(-min(q_rows, S) // 128) * 128)                    # whole 128-query blocks
+    f, g = full.t.view(2, Bn, S, D), part.t.view(2, Bn, S, D)
+    assert torch.equal(g[:, :, :rows], f[:, :, :rows]) and bool(torch.isfinite(f.float()).all())
+    assert bool((g[:, :, rows:] == 7.0).all())
+    with pytest.raises(RuntimeError):                                  # the relative-position modes have no such form
+        hip.attention(Q, part, Bn, S, Hh, hd, mode=1, grid=1, q_rows=1)
+
+
 def relpos_bias(q, rel_h, rel_w, L):
     """image_encoder.py:589-625 on (N, L*L, hd) queries."""
     idx = torch.arange(L)[:, None] - torch.arange(L)[None, :] + (L - 1)
