@@ -5,6 +5,7 @@
 //   MODE 2: waves 0..3 the MFMA trips, waves 4..7 the VALU trips (one of each kind per SIMD)
 //   MODE 3: every wave both, interleaved in one loop body (8 MFMAs + 32 FMAs per trip)
 //   MODE 4: waves 0..3 only, both interleaved (one wave per SIMD)
+//   MODE 5 / 6 / 7 (16 waves per CU, four per SIMD): every wave both / waves 0..7 MFMA and 8..15 VALU (two of each kind per SIMD) / MFMA only
 // If the two pipes overlap, MODE 2 takes max(MODE 0, MODE 1) / 2 per unit of work and MODE 3 takes max, not the sum.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_valu_overlap.hip -o tools/micro/bin/mfma_valu_overlap
 #include <hip/hip_runtime.h>
@@ -16,7 +17,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
-__global__ __launch_bounds__(512) void k(const half8* __restrict__ frag, float* out, int iters, float fa, float fb) {
+__global__ __launch_bounds__(MODE >= 5 ? 1024 : 512) void k(const half8* __restrict__ frag, float* out, int iters, float fa, float fb) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     half8 a[4], b[4];
     for (int i = 0; i < 4; ++i) { a[i] = frag[i * 64 + lane]; b[i] = frag[(4 + i) * 64 + lane]; }
@@ -24,8 +25,8 @@ __global__ __launch_bounds__(512) void k(const half8* __restrict__ frag, float* 
     float x[32];
     for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
     for (int i = 0; i < 32; ++i) x[i] = (float)(lane + i);
-    const bool do_m = MODE == 0 || MODE == 3 || (MODE == 2 && wave < 4) || (MODE == 4 && wave < 4);
-    const bool do_v = MODE == 1 || MODE == 3 || (MODE == 2 && wave >= 4) || (MODE == 4 && wave < 4);
+    const bool do_m = MODE == 0 || MODE == 3 || (MODE == 2 && wave < 4) || (MODE == 4 && wave < 4) || MODE == 5 || (MODE == 6 && wave < 8) || MODE == 7;
+    const bool do_v = MODE == 1 || MODE == 3 || (MODE == 2 && wave >= 4) || (MODE == 4 && wave < 4) || MODE == 5 || (MODE == 6 && wave >= 8);
     if (do_m && do_v) {
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -58,13 +59,13 @@ int main(int argc, char** argv) {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     half8* frag; float* out;
     hipMalloc(&frag, 8 * 64 * sizeof(half8));
-    hipMalloc(&out, (size_t)cus * 512 * sizeof(float));
+    hipMalloc(&out, (size_t)cus * 1024 * sizeof(float));
     { _Float16 h[8 * 64 * 8]; srand(1); for (auto& v : h) v = (_Float16)((rand() % 4096) / 1024.0f - 2.0f); hipMemcpy(frag, h, sizeof(h), hipMemcpyHostToDevice); }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const char* names[5] = {"MFMA only, 2 waves / SIMD", "VALU only, 2 waves / SIMD", "one MFMA wave + one VALU wave per SIMD", "both in every wave, 2 waves / SIMD",
-                            "both in one wave per SIMD"};
-    for (int mode = 0; mode < 5; ++mode) {
+    const char* names[8] = {"MFMA only, 2 waves / SIMD", "VALU only, 2 waves / SIMD", "one MFMA wave + one VALU wave per SIMD", "both in every wave, 2 waves / SIMD",
+                            "both in one wave per SIMD", "both in every wave, 4 waves / SIMD", "two MFMA waves + two VALU waves per SIMD", "MFMA only, 4 waves / SIMD"};
+    for (int mode = 0; mode < 8; ++mode) {
         const int iters = 200000;
         auto launch = [&]() {
             switch (mode) {
@@ -72,7 +73,10 @@ int main(int argc, char** argv) {
                 case 1: hipLaunchKernelGGL(k<1>, dim3(cus), dim3(512), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
                 case 2: hipLaunchKernelGGL(k<2>, dim3(cus), dim3(512), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
                 case 3: hipLaunchKernelGGL(k<3>, dim3(cus), dim3(512), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
-                default: hipLaunchKernelGGL(k<4>, dim3(cus), dim3(512), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
+                case 4: hipLaunchKernelGGL(k<4>, dim3(cus), dim3(512), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
+                case 5: hipLaunchKernelGGL(k<5>, dim3(cus), dim3(1024), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
+                case 6: hipLaunchKernelGGL(k<6>, dim3(cus), dim3(1024), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
+                default: hipLaunchKernelGGL(k<7>, dim3(cus), dim3(1024), 0, 0, frag, out, iters, 0.999f, 0.001f); break;
             }
         };
         launch(); hipDeviceSynchronize();
