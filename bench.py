@@ -196,7 +196,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "exact"), choices=["exact", "mixed", "fast"])
+    ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "exact"), choices=["exact", "mx", "mixed", "fast"])
     ap.add_argument("--geometry", default="demo", choices=["demo", "tiny", "hires1536"])
     ap.add_argument("--workload", default="cascade", choices=["cascade", "encoder"],
                     help="encoder = SAM ViT-H image encoder only (BASELINE configs[1] / [4] with --geometry hires1536)")
@@ -296,7 +296,9 @@ def cpu_model() -> str:
     return "unknown"
 
 
-DTYPE_NAMES = {"exact": "f32-grade (3x f16 split MFMA, f32 accumulate)", "mixed": "f32-grade GEMM/QK, f16 PV",
+DTYPE_NAMES = {"exact": "f32-grade (3x f16 split MFMA, f32 accumulate)",
+               "mx": "f32-grade (f16 hi.hi MFMA + block-scaled e4m3 MFMA for the two correction products in the ViT-H qkv / lin1 / lin2 GEMMs, "
+                     "3x f16 split elsewhere; f32 accumulate)", "mixed": "f32-grade GEMM/QK, f16 PV",
                "fast": "f16 operands, f32 accumulate"}
 
 

@@ -63,7 +63,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % BK_MIN) != 0) return CVLM_E_BADARG;
     if ((g.lda & 7) || (g.ldw & 7) || (g.stride_a & 7) || (g.stride_w & 7)) return CVLM_E_BADARG;
     if (g.split != 1 && g.split != 3) return CVLM_E_BADARG;
-    if (g.split == 3 && ((!g.a_lo && !g.a_il) || !g.w_lo)) return CVLM_E_BADARG;
+    if (g.split == 3 && ((!g.a_lo && !g.a_il && !g.a_mx) || !g.w_lo)) return CVLM_E_BADARG;
     if (!g.out_f32 && !g.out_hi) return CVLM_E_BADARG;
     if (g.ps_c2 > 0 && ((g.ps_c2 & 3) || g.ps_h <= 0 || g.ps_w <= 0)) return CVLM_E_BADARG;
     if (g.hm_S > 0 && ((g.hm_hd & 3) || g.hm_H <= 0 || (g.M % g.hm_S) || g.N != 3 * g.hm_H * g.hm_hd || !g.out_hi)) return CVLM_E_BADARG;
@@ -92,6 +92,19 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             return CVLM_E_UNSUPPORTED;
         if (g.a_il && (!g.w_il || (g.lda & 7) || g.lda < 2 * (int64_t)g.K)) return CVLM_E_UNSUPPORTED;
         if (g.res_il && !g.res_hi) return CVLM_E_BADARG;
+    }
+    if (g.a_mx || g.out_mx || g.res_mx) {
+        // mx images (ABI 10): split-3, one problem, the LDS-staged epilogues; whole 64-column groups
+        if (g.split != 3 || conv || g.batch > 1 || g.ps_c2 > 0 || g.a_il || (g.out_mx && g.out_il) || (g.res_mx && g.res_il) ||
+            (g.N & 7) || (g.ldoh & 7) || (g.stride_oh & 7) || (g.hm_S > 0 && ((g.hm_hd & 7) || g.hm_S < 256)) ||
+            (g.out_f32 && ((g.ldo & 3) || (g.stride_o & 3))) || (g.residual && ((g.ldr & 3) || (g.stride_r & 3))))
+            return CVLM_E_UNSUPPORTED;
+        if (g.a_mx && (!g.a_mxs || !g.w_mx || !g.w_mxs || (g.K & 63) || (g.lda & 7) || g.lda < 2 * (int64_t)g.K || (g.ldw_mx & 7) ||
+                       g.ldw_mx < 2 * (int64_t)g.K || (g.lda_s & 3) || (g.ldw_s & 3) || g.lda_s * 64 < g.K || g.ldw_s * 64 < g.K))
+            return CVLM_E_BADARG;
+        if (g.out_mx && (!g.out_hi || !g.out_mxs || g.hm_S > 0 || (g.N & 63) || (g.ldo_s & 3) || (g.out_lo && (g.ldol & 7))))
+            return CVLM_E_BADARG;
+        if (g.res_mx && (!g.res_hi || !g.res_lo || (g.ldrl & 7) || (g.ldrh & 7))) return CVLM_E_BADARG;
     }
     GemmParams p;
     p.a = g;
@@ -123,7 +136,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     // (For grids of several rounds whose last round is partial -- proj / lin2 of a batch of 8 -- the same split measured slower,
     // profiles/r03_colsplit_ab.log; that form is gone.)
     if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
-        g.M <= 4096 && !h2res) {
+        g.M <= 4096 && !h2res && !g.a_mx) {
         const int nby = (g.M + 255) / 256, nbx = (g.N + 255) / 256;
         const int c0 = nby > 0 ? 256 / nby : 0;                          // column tiles of the first launch: one round of tiles
         const int rest_ = g.N - c0 * 256;
@@ -226,7 +239,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     int small_ring = 0;                                               // > 0: slots of the deep LDS ring for a 128^2 launch of a small grid
     static int sk_env = env_int("CVLM_GEMM_SK", 1);
     if (live_env) sk_env = env_int("CVLM_GEMM_SK", 1);
-    if (g.split == 3 && !conv && p.a.batch == 1 && g.M <= 4096 && (variant_env == 0 || (variant_env == 1 && sk_env > 1))) {
+    if (g.split == 3 && !conv && p.a.batch == 1 && g.M <= 4096 && !g.a_mx && (variant_env == 0 || (variant_env == 1 && sk_env > 1))) {
         const double K = (double)g.K;
         const long t1 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
         const long t2 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
@@ -408,11 +421,36 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
         const bool lds_staged = ga.ps_c2 == 0 && (ga.N & 7) == 0 && (ga.hm_S == 0 || ((ga.hm_hd & 7) == 0 && ga.hm_S >= 128)) &&
                                 (ga.ldo & 3) == 0 && (ga.stride_o & 3) == 0 && (ga.ldr & 3) == 0 && (ga.stride_r & 3) == 0 &&
                                 (ga.ldoh & 7) == 0 && (ga.stride_oh & 7) == 0;
+        static int t192_env = env_int("CVLM_GEMM_T192", 1);
+        if (live_env) t192_env = env_int("CVLM_GEMM_T192", 1);
+        if (g.a_mx) {
+            // both operands mx: the staggered 256-column kernel in its unit form (gemm_kernel.h, MX), one instantiation per epilogue form;
+            // 192-row tiles under one round of 256-row ones (the h2-residual form, as above); K-parts of a partial last round are whole
+            // groups of 8 units
+            if (!lds_staged || p.a.batch != 1 || (g.M & 7) || (g.N & 7) || (int64_t)g.M * g.lda * 2 >= ((int64_t)1 << 32) ||
+                (int64_t)g.N * g.ldw_mx * 2 >= ((int64_t)1 << 32))
+                return CVLM_E_UNSUPPORTED;
+            const long t5 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256), t6 = (long)((g.M + 191) / 192) * ((g.N + 255) / 256);
+            const bool use192 = t192_env && h2res && t5 <= 256 && t6 <= 256 && t6 > t5 && g.M > 4096;
+            p.tail_rem = 0; p.tail_split = 1; extra_blocks = 0;
+            if (!use192 && tail_env && have_ws) {
+                const int rem = (int)(t5 % 256);
+                int S = tail_parts(rem, g.K);
+                while (S > 1 && (g.K / 32 + 7) / 8 < 2 * S) --S;
+                if (S >= 2) {
+                    p.tail_rem = rem; p.tail_split = S;
+                    p.flags = (unsigned*)g.workspace;
+                    p.ws = (float*)((unsigned char*)g.workspace + TAIL_FLAG_BYTES);
+                    extra_blocks = rem * (S - 1);
+                }
+            }
+            p.group_m = g.K >= 4096 ? 2 : 4;
+            const int probe = variant_env >= 100 ? variant_env - 100 : 0;          /* probe builds: tools/probe_gemm_mx.py */
+            return launch_mx(p, use192 ? 6 : 8, fold ? 1 : (h2res ? 2 : 0), extra_blocks, probe, s);
+        }
         // 192 x 256 tiles (MT = 6, same staggered loop) for grids UNDER one round of 256^2 tiles: the CLIP out_proj / c_proj of the
         // fused 16-image forward are 37 x 4 = 148 tiles on 256 CUs; 49 x 4 = 196 tiles of 192 rows put 48 more CUs to work and
         // every workgroup finishes a quarter earlier.  Only the h2-residual form is instantiated (what those launches use).
-        static int t192_env = env_int("CVLM_GEMM_T192", 1);
-        if (live_env) t192_env = env_int("CVLM_GEMM_T192", 1);
         if (variant == 7 && variant_env == 0 && t192_env && h2res && lds_staged && p.a.batch == 1 && p.tail_rem == 0 && g.M > 4096) {
             const long t5 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256), t6 = (long)((g.M + 191) / 192) * ((g.N + 255) / 256);
             if (t5 <= 256 && t6 <= 256 && t6 > t5) {

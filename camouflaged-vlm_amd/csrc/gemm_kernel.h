@@ -55,8 +55,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // bytes], 16-byte chunks of row r permuted by ^ ((r >> 1) & 7) (the conflict-free image of the 128-byte-row loop); chunks 0-3 of a
 // row are the hi plane's k 0-31, chunks 4-7 the lo plane's.  Same fragments, same MFMAs, same bits.
 template <int SPLIT, int WM, int WN, int NSTAGE, int BK, int DBG = 0, int MT = 4, bool PERSIST = false, int EPI = -1, bool CONV = false,
-          bool SK = false, bool WIL = false, bool AIL = false>
+          bool SK = false, bool WIL = false, bool AIL = false, bool MX = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmParams p) {
+    // MX (ABI 10, cvlm_gemm_args.a_mx / w_mx): both operands are mx images -- per row and 64 k-elements one 128-byte line of fp16 hi
+    // values and one 128-byte line of e4m3 bytes (hi8 | lo8).  The ring's K-tiles become UNITS of one line per row, alternately an f16
+    // unit (two 16x16x32 f16 MFMAs per output tile: k 0-31 and 32-63 of hi.hi) and an fp8 unit (ONE v_mfma_scale_f32_16x16x128_f8f6f4
+    // per output tile whose K = 128 is [Whi8 . Alo8 | Wlo8 . Ahi8] over the same 64 k): 2048 matrix-pipe cycles per wave and 64 k
+    // instead of 3072, at 0.65 x the joules (profiles/r05_power_formats.log).  Staging, LDS image, fragment addresses and the
+    // accumulator layout are those of the WIL + AIL form: same bytes per row and unit, same ds_read_b128 pattern.
+    static_assert(!MX || (WIL && AIL && NSTAGE == 5 && SPLIT == 3 && !PERSIST && !SK && !CONV && (MT % 2) == 0), "mx operands: the staggered 256-column kernel");
     static_assert(!WIL || (SPLIT == 3 && BK == 32 && !CONV && NSTAGE != 4 && NSTAGE != 6), "interleaved weights: split-3 kernels with 32-wide K-tiles");
     // AIL (cvlm_gemm_args.a_il): the same for the ACTIVATION operand -- a_hi is an image [M][K / 32][plane][32] (what an out_il launch
     // or cvlm_row_stats_split with il wrote), lda its row stride in halves; LDS region [BM rows][128 bytes], same chunk permutation.
@@ -89,11 +96,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     const int z = blockIdx.y;
     const half_t* Ahi = (const half_t*)g.a_hi + (int64_t)z * g.stride_a;
     const half_t* Alo = (const half_t*)g.a_lo + (int64_t)z * g.stride_a;
-    const half_t* Whi = WIL ? (const half_t*)g.w_il : (const half_t*)g.w_hi + (int64_t)z * g.stride_w;
+    const half_t* Whi = MX ? (const half_t*)g.w_mx : WIL ? (const half_t*)g.w_il : (const half_t*)g.w_hi + (int64_t)z * g.stride_w;
     const half_t* Wlo = (const half_t*)g.w_lo + (int64_t)z * g.stride_w;
 
     // ---- per-tile state (set_tile): coordinates, K range, DMA source of every staging instruction of this wave
     int bm = 0, bn = 0, kpart = 0, kparts = 1, tail_j = 0, nk = 0;
+    [[maybe_unused]] int k0_units = 0;                                // MX: first unit of this workgroup's K range (a multiple of 8)
     const half_t* src[PER_WAVE];
     int dst_off[PER_WAVE];                                            // stage layout: [Ahi][Alo][Whi][Wlo]; instruction i covers 16 rows x 64 B
     // WIL: K advance of staging instruction j in halves per K-tile element -- weight instructions walk the interleaved image, where a
@@ -185,15 +193,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             }
         }
         nk = g.K / BK;
+        k0_units = 0;
         if ((NSTAGE == 5 || SK) && kparts > 1) {                         // this workgroup's share of the K-tiles
-            const int base = nk / kparts, extra = nk - base * kparts;
-            const int k0 = kpart * base + (kpart < extra ? kpart : extra);
-            nk = base + (kpart < extra ? 1 : 0);
+            // MX: parts are whole groups of 8 units (4 unit pairs = one dword of scale bytes per fragment row)
+            const int nku = MX ? (nk + 7) / 8 : nk;
+            const int base = nku / kparts, extra = nku - base * kparts;
+            int k0 = kpart * base + (kpart < extra ? kpart : extra);
+            int mine = base + (kpart < extra ? 1 : 0);
+            if (MX) { k0 *= 8; mine = mine * 8 < nk - k0 ? mine * 8 : nk - k0; k0_units = k0; }
+            nk = mine;
 #pragma unroll
             for (int j = 0; j < PER_WAVE; ++j) src[j] += (int64_t)k0 * BK * kmul(j);
         }
     };
-    auto set_tile = [&](int pid) { set_tile_(pid, Ahi, Alo, Whi, Wlo, g.lda, WIL ? g.ldw_il : g.ldw, g.M, g.N); };
+    auto set_tile = [&](int pid) { set_tile_(pid, Ahi, Alo, Whi, Wlo, g.lda, MX ? g.ldw_mx : WIL ? g.ldw_il : g.ldw, g.M, g.N); };
     int vblk = blockIdx.x;
     set_tile(vblk);
 
@@ -415,6 +428,167 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             wait_vmcnt<0>();                                             // tile t+1 landed (this wave's share)
             __builtin_amdgcn_s_barrier();
         }
+    } else if constexpr (NSTAGE == 5 && MX) {
+        // The staggered two-slot loop of the branch below over UNITS (see the template comment): even units multiply fp16 lines, odd
+        // units e4m3 lines; eight units (four unit pairs = the four scale bytes of one dword) are one pass of the loop body.
+        //   fragment registers: wf[i] = (chunk fq | chunk 4 + fq) of weight rows, af[i] = (chunk 4 + fq | chunk fq) of activation rows
+        //   f16 unit : chunk c of a line = k 8c .. 8c + 7:  acc += W(chunk fq) . A(chunk fq) + W(chunk 4 + fq) . A(chunk 4 + fq)
+        //   fp8 unit : line = (hi8 k 0-63 | lo8 k 0-63).  The instruction's lane (r, q) supplies k' = 16q .. 16q + 15 with its first 16
+        //              bytes and k' = 64 + 16q .. with its second 16 (tools/micro/mx_semantics.hip, measured), so with the registers
+        //              above its K = 128 is [Whi8 (k 0-63) | Wlo8 (k 0-63)] . [Alo8 (k 0-63) | Ahi8 (k 0-63)]: both corrections.
+        //   scales   : the E8M0 byte of k'-block b (32 elements) comes from lane (r, b): weight lanes read scale plane fq (hi8 first),
+        //              activation lanes plane fq ^ 2 (lo8 first); one dword = the bytes of four unit pairs, op_sel picks the pair.
+        const bool grpB = __builtin_amdgcn_readfirstlane(tid) >= (NWAVE / 2) * 64;
+        constexpr int MH = MT / 2;
+        intx8 wf[4], af[MH];
+        constexpr bool DMA_ONLY = DBG == 2 || (DBG >= 12 && DBG <= 15);
+        if (DBG == 9 || DMA_ONLY) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = intx8{lane, i, lane, 1, 2, lane, 3, 4};
+#pragma unroll
+            for (int i = 0; i < MH; ++i) af[i] = intx8{i, lane, 5, lane, 6, 7, lane, 8};
+        }
+        int sw[4], sa[MT];
+        // DMA sources without per-instruction vector registers: staging instruction i of this workgroup covers 8 rows x 128 bytes, row
+        // block i of the tile; a lane's source is  base + (first row of the block) * pitch + unit * 128  -- all scalar -- plus
+        // (lane / 8) * pitch + (chunk the lane's LDS position holds) * 16, and the chunk permutation ^ ((row >> 1) & 7) depends on the
+        // block only through its parity: two vector registers per operand instead of the general kernel's 32 (64-bit pointers), which
+        // this loop needs for the scale words.  Rows come in whole blocks (the launcher checks M % 8 == 0, N % 8 == 0 and that both
+        // images are below 4 GiB), so the clamp of the last tile is scalar too.
+        unsigned va[2], vw[2];
+        {
+            const int r = lane >> 3, pos8 = lane & 7;
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                va[par] = (unsigned)r * (unsigned)g.lda * 2u + (unsigned)((pos8 ^ (4 * par + (r >> 1))) * 16);
+                vw[par] = (unsigned)r * (unsigned)g.ldw_mx * 2u + (unsigned)((pos8 ^ (4 * par + (r >> 1))) * 16);
+            }
+        }
+        const int k0_bytes = k0_units * 128;
+        auto dma_piece = [&](int j, int tn, unsigned char* dst) {
+            const int i = wave * PER_WAVE + j;                              // wave-uniform
+            const bool isW = i >= NPA * A_INSTR;
+            const int blk = isW ? i - NPA * A_INSTR : i;
+            int row = (isW ? bn : bm) + blk * 8;
+            const int lim = (isW ? g.N : g.M) - 8;
+            row = row < lim ? row : lim;
+            const char* base = (const char*)(isW ? Whi : Ahi) + (int64_t)row * (isW ? g.ldw_mx : g.lda) * 2 + k0_bytes + (int64_t)tn * 128;   // a unit is 128 bytes of a row
+            unsigned o = isW ? vw[blk & 1] : va[blk & 1];
+            asm volatile("" : "+s"(base), "+v"(o));  // keep the address a scalar base + a 32-bit vector offset (left alone, the zero-extended offsets are hoisted as 64-bit pairs)
+            // probe builds: DBG 12 .. 15 = the DMA-only form with a cache policy on the load (sc0, nt, sc1, sc0 sc1)
+            constexpr int AUX = DBG == 12 ? 1 : DBG == 13 ? 2 : DBG == 14 ? 16 : DBG == 15 ? 17 : 0;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + o), (LDS_AS void*)(dst + dst_off[j]), 16, 0, AUX);
+        };
+        const unsigned char* a_s = (const unsigned char*)g.a_mxs;
+        const unsigned char* w_s = (const unsigned char*)g.w_mxs;
+        auto load_scales = [&](int grp) {                       // grp: index of the 8-unit group within the whole K range
+            // addresses are rebuilt from the lane's row index at every call (12 loads per 8 units): kept across the loop they are 24
+            // registers this kernel does not have (the compiler spilled them and reloaded each behind a vmcnt(0))
+            int frx = fr;
+            asm volatile("" : "+v"(frx));
+            const unsigned wstep = 4u * (unsigned)g.ldw_s, astep = 4u * (unsigned)g.lda_s;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int r = bn + wn * 64 + i * 16 + frx;
+                r = r < g.N ? r : g.N - 1;
+                sw[i] = *(const int*)(w_s + ((unsigned)r * wstep + (unsigned)fq * (unsigned)g.ldw_s + 4u * (unsigned)grp));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                int r = bm + wm * WROWS + i * 16 + frx;
+                r = r < g.M ? r : g.M - 1;
+                sa[i] = *(const int*)(a_s + ((unsigned)r * astep + (unsigned)(fq ^ 2) * (unsigned)g.lda_s + 4u * (unsigned)grp));
+            }
+        };
+        // the compiler's own wait for the scale loads lands HERE, next to a vmcnt(0) this wave executes anyway (it cannot see the
+        // counted waits of this loop: left to itself it would wait at the first fp8 instruction, in front of group B's P0)
+        auto touch_scales = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(sw[i]));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(sa[i]));
+        };
+        auto half_of = [&](const intx8& v, int h) -> half8 {
+            return __builtin_bit_cast(half8, h ? intx4{v[4], v[5], v[6], v[7]} : intx4{v[0], v[1], v[2], v[3]});
+        };
+        auto cat = [&](half8 lo, half8 hi) -> intx8 {
+            const intx4 a = __builtin_bit_cast(intx4, lo), b = __builtin_bit_cast(intx4, hi);
+            return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto read_w = [&](const unsigned char* cur) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = cat(w_frag(cur, i, 0, 0), w_frag(cur, i, 1, 0));
+        };
+        auto read_a = [&](const unsigned char* cur, int mh) {
+#pragma unroll
+            for (int i = 0; i < MH; ++i) af[i] = cat(a_frag(cur, mh * MH + i, 1, 0), a_frag(cur, mh * MH + i, 0, 0));
+        };
+        auto mfma_half = [&](auto kind_c, int mh, int tn, int sn) {   // kind 0: f16 unit; 1 .. 4: fp8 unit, scale byte kind - 1
+            constexpr int KIND = decltype(kind_c)::value;
+            const bool dma = tn >= 0 && tn < nk && DBG != 1;
+            unsigned char* nxt = smem + sn * STAGE;
+#pragma unroll
+            for (int mt = 0; mt < MH; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    floatx4 c = acc[mh * MH + mt][nt];
+                    if (DMA_ONLY || (DBG == 10 && KIND != 0) || (DBG == 11 && KIND == 0)) continue;
+                    if (KIND == 0) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(half_of(wf[nt], 0), half_of(af[mt], 1), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(half_of(wf[nt], 1), half_of(af[mt], 0), c, 0, 0, 0);
+                    } else {
+                        constexpr int SEL = KIND > 0 ? KIND - 1 : 0;
+                        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[nt], af[mt], c, 0, 0, SEL, sw[nt], SEL, sa[mh * MH + mt]);
+                    }
+                    acc[mh * MH + mt][nt] = c;
+                }
+                if (dma) {
+#pragma unroll
+                    for (int j = (mt * PER_WAVE) / MH; j < ((mt + 1) * PER_WAVE) / MH; ++j) dma_piece(j, tn, nxt);
+                }
+            }
+        };
+        auto unit = [&](auto kind_c, auto first_c, int t) {
+            constexpr bool FIRST = decltype(first_c)::value;             // first unit of a group: the scale loads were just issued
+            const unsigned char* cur = smem + (t & 1) * STAGE;
+            // probe builds: DBG 1 no DMA in the steady state, 2 DMA only, 9 no fragment reads (stale registers), 10 / 11 only the f16 / fp8 units multiply
+            if (!DMA_ONLY && DBG != 9) { read_w(cur); read_a(cur, 0); }
+            mfma_half(kind_c, 0, grpB ? -1 : t + 1, (t + 1) & 1);
+            if (!DMA_ONLY && DBG != 9) read_a(cur, 1);
+            if (grpB) { wait_vmcnt<0>(); if (FIRST) touch_scales(); }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfma_half(kind_c, 1, grpB ? t + 2 : -1, t & 1);
+            if (!grpB) { wait_vmcnt<0>(); if (FIRST) touch_scales(); }
+            __builtin_amdgcn_s_barrier();
+        };
+        typedef std::integral_constant<int, 0> k0_t;
+        typedef std::integral_constant<bool, true> yes_t;
+        typedef std::integral_constant<bool, false> no_t;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) dma_piece(j, 0, smem);
+        if (grpB && nk > 1) {
+#pragma unroll
+            for (int j = 0; j < PER_WAVE; ++j) dma_piece(j, 1, smem + STAGE);
+            wait_vmcnt<PER_WAVE>();
+        } else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (grpB) __builtin_amdgcn_s_barrier();                  // B starts one phase late
+        for (int tg = 0; tg < nk; tg += 8) {                     // nk is even (K % 64 == 0; parts are whole groups)
+            load_scales((k0_units + tg) >> 3);
+            unit(k0_t{}, yes_t{}, tg);
+            unit(std::integral_constant<int, 1>{}, no_t{}, tg + 1);
+            if (tg + 2 >= nk) break;
+            unit(k0_t{}, no_t{}, tg + 2);
+            unit(std::integral_constant<int, 2>{}, no_t{}, tg + 3);
+            if (tg + 4 >= nk) break;
+            unit(k0_t{}, no_t{}, tg + 4);
+            unit(std::integral_constant<int, 3>{}, no_t{}, tg + 5);
+            if (tg + 6 >= nk) break;
+            unit(k0_t{}, no_t{}, tg + 6);
+            unit(std::integral_constant<int, 4>{}, no_t{}, tg + 7);
+        }
+        if (!grpB) __builtin_amdgcn_s_barrier();                  // match B's extra leading barrier
     } else if (NSTAGE == 5) {
         // Two slots, wave groups staggered by half a K-tile (MT = 8, BK = 32).  Waves 0..3 (group A) and 4..7
         // (group B) share SIMDs pairwise (wave w and w+4).  Each K-tile has two phases per wave,
@@ -781,6 +955,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     int m = mw + mt_ * 16 + rowh + 8 * i;
                     m = m < g.M ? m : g.M - 1;                        // clamped, always a valid address: masked at the use
                     const int nc = nh < g.N ? nh : 0;
+                    if (g.res_mx) {                                   // hi halves of the mx image, lo from the fp16 plane beside it
+                        res_h[buf][i] = *(const half8*)((const half_t*)g.res_hi + (int64_t)m * g.ldrh + ((nc >> 6) << 7) + (nc & 63));
+                        res_l[buf][i] = *(const half8*)((const half_t*)g.res_lo + (int64_t)m * g.ldrl + nc);
+                        continue;
+                    }
                     const int64_t ro = (int64_t)m * g.ldrh + (g.res_il ? ((nc >> 5) << 6) + (nc & 31) : nc);
                     res_h[buf][i] = *(const half8*)((const half_t*)g.res_hi + ro);
                     res_l[buf][i] = g.res_il ? *(const half8*)((const half_t*)g.res_hi + ro + 32) : *(const half8*)((const half_t*)g.res_lo + ro);
@@ -894,6 +1073,52 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                                 hi4[j] = a; lo4[j] = b2;
                             }
                             const half8 hi = __builtin_bit_cast(half8, hi4), lo = __builtin_bit_cast(half8, lo4);
+                            if (g.out_mx) {
+                                // mx image (include/cvlm.h ABI 10): this lane's 8 columns are a quarter of a 32-column scale block, the
+                                // four lanes of the block are a DPP quad.  E = exponent field of the block's largest |hi| (as f32, at
+                                // least 103) - 7: every hi / 2^(E - 127) is below 256, every lo / 2^(E - 138) below 128 -- inside e4m3.
+                                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                                typedef short s2v __attribute__((ext_vector_type(2)));
+                                // (element reads go through scalars: __builtin_bit_cast of a vector ELEMENT expression reads the vector's first bytes)
+                                h2v hv[4], lv[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const unsigned hj = hi4[j], lj = lo4[j];
+                                    hv[j] = __builtin_bit_cast(h2v, hj);
+                                    lv[j] = __builtin_bit_cast(h2v, lj);
+                                }
+                                h2v mx2 = __builtin_elementwise_abs(hv[0]);
+#pragma unroll
+                                for (int j = 1; j < 4; ++j) mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_abs(hv[j]));
+                                float bmax = fmaxf((float)mx2[0], (float)mx2[1]);
+                                bmax = fmaxf(bmax, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bmax), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+                                bmax = fmaxf(bmax, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bmax), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+                                int ex = (__builtin_bit_cast(int, bmax) >> 23) & 0xff;
+                                ex = (ex < 103 ? 103 : ex) - 7;
+                                const float s_hi = __builtin_bit_cast(float, ex << 23), s_lo = __builtin_bit_cast(float, (ex - 11) << 23);
+                                s2v h8a = {0, 0}, h8b = {0, 0}, l8a = {0, 0}, l8b = {0, 0};
+                                h8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8a, hv[0], s_hi, false);
+                                h8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8a, hv[1], s_hi, true);
+                                h8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8b, hv[2], s_hi, false);
+                                h8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8b, hv[3], s_hi, true);
+                                l8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8a, lv[0], s_lo, false);
+                                l8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8a, lv[1], s_lo, true);
+                                l8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8b, lv[2], s_lo, false);
+                                l8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8b, lv[3], s_lo, true);
+                                if (DBG == 3) { asm volatile("" ::"v"(hi), "v"(h8a), "v"(h8b), "v"(l8a), "v"(l8b)); continue; }
+                                unsigned char* row = (unsigned char*)g.out_hi + ((int64_t)m * g.ldoh + ((nh >> 6) << 7)) * 2;      // the 256-byte group
+                                const int j8 = (nh & 63) >> 3;
+                                *(half8*)(row + j8 * 16) = hi;
+                                *(uint2*)(row + 128 + j8 * 8) = make_uint2(__builtin_bit_cast(unsigned, h8a), __builtin_bit_cast(unsigned, h8b));
+                                *(uint2*)(row + 192 + j8 * 8) = make_uint2(__builtin_bit_cast(unsigned, l8a), __builtin_bit_cast(unsigned, l8b));
+                                if ((lane & 3) == 0) {
+                                    unsigned char* sc = (unsigned char*)g.out_mxs + ((int64_t)m * 4 + (j8 >> 2)) * g.ldo_s + (nh >> 6);
+                                    sc[0] = (unsigned char)ex;
+                                    sc[2 * g.ldo_s] = (unsigned char)(ex - 11);
+                                }
+                                if (g.out_lo) *(half8*)((half_t*)g.out_lo + (int64_t)m * g.ldol + nh) = lo;
+                                continue;
+                            }
                             int64_t off = (int64_t)m * g.ldoh + (g.out_il ? ((nh >> 5) << 6) + (nh & 31) : nh);   // out_il: [m][n / 32][plane][32]
                             if (g.hm_S > 0) {                              // row part: rows advance by mt * 16 + 8 * i < hm_S
                                 int tk = hm_t + mt * 16 + 8 * i, bi = hm_b;
@@ -1065,3 +1290,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
     CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 1, false, -1, false, false, true, true)             \
     CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 2, false, -1, false, false, true, true)             \
     CVLM_GEMM_IL_KERNEL(PFX, 3, 4, 2, 14, 32, 0, 2, false, -1, false, true, true, true)
+
+// The mx kernels (ABI 10: both operands mx images, staggered 256-column loop) are instantiated and launched in gemm_mx.hip, a third
+// translation unit: mt = 8 (256-row tiles) or 6 (192-row tiles, h2-residual form only), epi = 1 (LayerNorm fold) or 2 (h2 residual +
+// row statistics); probe (probe builds only) = DBG form of the fold kernel.  p.tail_rem / tail_split / ws / flags are set by the caller.
+namespace cvlm_gemm_k { int launch_mx(GemmParams& p, int mt, int epi, int extra_blocks, int probe, hipStream_t s); }

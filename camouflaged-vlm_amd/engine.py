@@ -25,14 +25,17 @@ from .spec import ClipGeometry, SamGeometry
 
 @dataclass(frozen=True)
 class Precision:
-    """split = 3: hi*hi + lo*hi + hi*lo products (fp32-grade, the parity mode); 1: fp16 operands."""
+    """split = 3: hi*hi + lo*hi + hi*lo products (fp32-grade, the parity mode); 1: fp16 operands.
+    mx: the GEMMs whose operands only GEMMs touch (qkv / lin1 / lin2 of the ViT-H blocks) form the two correction products lo*hi and
+    hi*lo on the block-scaled e4m3 matrix instruction (include/cvlm.h ABI 10); everything else is split = 3."""
     gemm: int = 3
     qk: int = 3
     pv: int = 3
+    mx: bool = False
 
     @staticmethod
     def named(name: str) -> "Precision":
-        return {"exact": Precision(3, 3, 3), "fast": Precision(1, 1, 1), "mixed": Precision(3, 3, 1)}[name]
+        return {"exact": Precision(3, 3, 3), "mx": Precision(3, 3, 3, True), "fast": Precision(1, 1, 1), "mixed": Precision(3, 3, 1)}[name]
 
 
 # Static power-of-two scales that keep UNBOUNDED activations inside fp16 range when they become h2 GEMM operands
@@ -84,6 +87,15 @@ class Workspace:
         flat = self._get("h2", name, 2 * M * C, torch.float16, False)
         return hip.H2IL(flat.view(M, 2 * C))
 
+    def h2mx(self, name: str, M: int, C: int, lo_plane: bool = False) -> hip.H2MX:
+        """Activation as an mx operand (include/cvlm.h ABI 10): image uint8 [M][4 * C], block exponents uint8 [M][4][pitch] and,
+        on request, the fp16 lo plane [M][C] beside it (the residual stream)."""
+        img = self._get("u8", name, 4 * M * C, torch.uint8, False).view(M, 4 * C)
+        su = hip.mx_scale_pitch(C)
+        sc = self._get("u8", name + ".scales", 4 * M * su, torch.uint8, True).view(M, 4, su)
+        lo = self._get("h2", name + ".lo", M * C, torch.float16, False).view(M, C) if lo_plane else None
+        return hip.H2MX(img, sc, lo, C)
+
     def scratch(self, name: str, nbytes: int) -> Optional[torch.Tensor]:
         return self._get("u8", name, nbytes, torch.uint8, False) if nbytes > 0 else None
 
@@ -100,7 +112,7 @@ class Linear:
     """Packed weight of one NT GEMM: rows scaled by a power of two so the lo plane stays in fp16's
     normal range, K zero-padded to a multiple of 32, optional N padding (zero rows)."""
 
-    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device, n_pad: int = 0, k_pad: int = 0, il: bool = True):
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device, n_pad: int = 0, k_pad: int = 0, il: bool = True, mx: bool = False):
         w = w.detach().float().reshape(w.shape[0], -1).cpu()
         N, K = w.shape
         self.N = max(N, n_pad)
@@ -111,7 +123,13 @@ class Linear:
         e = 0 if mx == 0.0 else int(math.floor(math.log2(2048.0 / mx)))
         e = max(min(e, 24), -24)
         self.alpha = float(2.0 ** (-e))
-        self.w = H2(H2.pack(wp * (2.0 ** e)).t.to(device))
+        planes = H2.pack(wp * (2.0 ** e))
+        self.w = H2(planes.t.to(device))
+        # third image: the mx operand (cvlm_gemm_args.w_mx, ABI 10) for the launches whose activation is an mx image
+        self.w_mx = None
+        if mx and self.K % 64 == 0 and self.N * self.K >= (1 << 18):
+            m = hip.H2MX.from_planes(planes)
+            self.w_mx = hip.H2MX(m.t.to(device), m.s.to(device), None, m.C)
         # second image with the planes interleaved per 32 k-elements (cvlm_gemm_args.w_il, ABI 6): what the big-tile kernels stage
         # the weight from; small matrices never reach those kernels, and `il=False` marks weights that only the tap / fallback
         # schedules launch (the unfused twins of LayerNorm-folded GEMMs): they stay planar and cost no second copy
@@ -128,11 +146,11 @@ class LnLinear(Linear):
         Linear(LN(x)) = rstd * (x . W'^T - mu * colsum) + bias',   W' = W . diag(gamma),  bias' = bias + W . beta,
     colsum[n] = sum_k W'[n][k] -- taken from the PACKED planes so that it is the sum of exactly the numbers the MFMAs see."""
 
-    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, device):
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, device, mx: bool = False):
         w = w.detach().double().reshape(w.shape[0], -1).cpu()
         g, be = gamma.detach().double().cpu(), beta.detach().double().cpu()
         b2 = (b.detach().double().cpu() if b is not None else torch.zeros(w.shape[0], dtype=torch.float64)) + w @ be
-        super().__init__((w * g[None, :]).float(), b2.float(), device)
+        super().__init__((w * g[None, :]).float(), b2.float(), device, mx=mx)
         self.colsum = (self.w.t.double().sum(0).sum(1) * self.alpha).float().contiguous()
 
 
@@ -157,7 +175,7 @@ class _Base:
             kw["bias"] = lin.bias
         w_il = lin.w_il if kw.get("batch", 1) == 1 and kw.get("conv3x3") is None and "ldw" not in kw else None
         hip.gemm(a, lin.w, M, kw.pop("N", lin.N), lin.K, alpha=alpha * lin.alpha,
-                 workspace=self.ws.gemm_ws() if self.ksplit else None, w_il=w_il, **kw)
+                 workspace=self.ws.gemm_ws() if self.ksplit else None, w_il=w_il, w_mx=lin.w_mx if getattr(a, "mx", False) else None, **kw)
 
     def attention(self, qkv: H2, out: H2, B: int, S: int, heads: int, hd: int, **kw) -> None:
         hip.attention(qkv, out, B, S, heads, hd,
@@ -215,8 +233,9 @@ class SamEncoder(_Base):
         shw = torch.zeros(D, self.PK)
         shw[:, :Pd] = sd[P + pg + "shared_mlp.weight"].detach().float().cpu()
         shb = sd[P + pg + "shared_mlp.bias"].detach().float().cpu()
+        mx = precision.mx
         self.lin2cat = [Linear(torch.cat([sd[P + f"blocks.{i}.mlp.lin2.weight"].detach().float().cpu(), shw], 1),
-                               sd[P + f"blocks.{i}.mlp.lin2.bias"].detach().float().cpu() + shb, device)
+                               sd[P + f"blocks.{i}.mlp.lin2.bias"].detach().float().cpu() + shb, device, mx=mx)
                         for i in range(g.depth - 1)]
         # LayerNorm folded into the GEMMs that consume it + the residual stream kept in h2 between them: no LayerNorm
         # kernels inside the blocks (64 launches, 4.5 ms per step at B = 8).  CVLM_LN_FOLD=0 (both towers) builds no folded weights
@@ -246,15 +265,15 @@ class SamEncoder(_Base):
                 # with the fold on, qkv / lin1 (and lin2 of every block but the last: lin2cat carries it) are launched by the tap
                 # schedule and the refusal fallback only: planar, no 128-byte-row image (~1 GB at ViT-H)
                 qkv=Linear(qkv_w, qkv_b, device, il=not self.ln_fold), proj=L(b + "attn.proj"), lin1=L(b + "mlp.lin1", il=not self.ln_fold),
-                lin2=L(b + "mlp.lin2", il=not self.ln_fold or i == g.depth - 1),
+                lin2=L(b + "mlp.lin2", il=not self.ln_fold or i == g.depth - 1, mx=mx and i == g.depth - 1),
                 pad=H2(H2.pack(qkv_b).t.to(device)),
                 rel_h=H2(H2.pack(sd[P + b + "attn.rel_pos_h"].detach().float().cpu() / qs).t.to(device)),
                 rel_w=H2(H2.pack(sd[P + b + "attn.rel_pos_w"].detach().float().cpu() / qs).t.to(device)),
                 window=0 if i in g.global_attn_indexes else g.window_size)
             if self.ln_fold:
-                blk["qkv_f"] = LnLinear(qkv_w, qkv_b, sd[P + b + "norm1.weight"], sd[P + b + "norm1.bias"], device)
+                blk["qkv_f"] = LnLinear(qkv_w, qkv_b, sd[P + b + "norm1.weight"], sd[P + b + "norm1.bias"], device, mx=mx)
                 blk["lin1_f"] = LnLinear(sd[P + b + "mlp.lin1.weight"], sd[P + b + "mlp.lin1.bias"],
-                                         sd[P + b + "norm2.weight"], sd[P + b + "norm2.bias"], device)
+                                         sd[P + b + "norm2.weight"], sd[P + b + "norm2.bias"], device, mx=mx)
             self.blocks.append(blk)
         self.neck0 = L("neck.0")
         w2 = sd[P + "neck.2.weight"].detach().float().cpu()                   # (O, I, 3, 3) -> (O, ky, kx, I)
@@ -405,9 +424,23 @@ class SamEncoder(_Base):
                   all(b["qkv_f"].w_il is not None and b["lin1_f"].w_il is not None for b in self.blocks) and
                   self.blocks[-1]["lin2"].w_il is not None and all(l.w_il is not None for l in self.lin2cat))
         xo = xh                                                      # where proj / lin2 write the stream
+        x_last = None
         if use_il:
             xo = ws.h2il("xh_il", M, D)
             hid = ws.h2il("hid_il", M, HK)
+            hid_prm = hid.cols(g.mlp_dim)
+        # Precision `mx` (include/cvlm.h ABI 10): the same two activations as mx operands -- fp16 hi values + e4m3 hi8 / lo8 bytes with
+        # block exponents --, so that qkv, lin1 and lin2 (92 % of the blocks' GEMM flops) run hi.hi on fp16 and both correction
+        # products on the block-scaled e4m3 instruction.  The stream keeps its fp16 lo plane beside the image: proj / lin2 read and
+        # write it as their h2 residual at full 22 bits.  Block 0's qkv still reads the planar seed; the last lin2 writes the
+        # 128-byte-row image the neck reads.
+        use_mx = (use_il and pr.mx and D % 64 == 0 and HK % 64 == 0 and self.blocks[-1]["lin2"].w_mx is not None and
+                  all(b["qkv_f"].w_mx is not None and b["lin1_f"].w_mx is not None for b in self.blocks) and
+                  all(l.w_mx is not None for l in self.lin2cat))
+        if use_mx:
+            x_last = xo
+            xo = ws.h2mx("xh_mx", M, D, lo_plane=True)
+            hid = ws.h2mx("hid_mx", M, HK)
             hid_prm = hid.cols(g.mlp_dim)
         hk = {} if use_il else {"ldoh": HK}                          # the image carries its own row stride
         for i, blk in enumerate(self.blocks):
@@ -431,8 +464,10 @@ class SamEncoder(_Base):
                 self.gemm(hid, self.lin2cat[i], M, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
                           alpha=1.0 / HID_SCALE, row_stats=pcs)
             else:
-                self.gemm(hid, blk["lin2"], M, lda=HK, out_h2=xh, residual_h2=(xh, inv), out_scale=X_SCALE,
+                self.gemm(hid, blk["lin2"], M, lda=HK, out_h2=xh if x_last is None else x_last, residual_h2=(xh, inv), out_scale=X_SCALE,
                           alpha=1.0 / HID_SCALE)
+                if x_last is not None:
+                    xh = x_last
             self._hook(i)
         return self._neck(xh, B)
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
     "cvlm_ln_stats_merge", "cvlm_small_attention_h2", "cvlm_prob_quantise", "cvlm_prob_moments", "cvlm_prob_wfm",
 ]
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class GemmArgs(C.Structure):
@@ -48,6 +48,10 @@ class GemmArgs(C.Structure):
         ("conv_h", C.c_int32), ("conv_w", C.c_int32), ("conv_c", C.c_int32),
         ("w_il", C.c_void_p), ("ldw_il", C.c_int64),
         ("a_il", C.c_int32), ("out_il", C.c_int32), ("res_il", C.c_int32),
+        ("a_mx", C.c_int32), ("out_mx", C.c_int32), ("res_mx", C.c_int32),
+        ("a_mxs", C.c_void_p), ("lda_s", C.c_int64),
+        ("w_mx", C.c_void_p), ("ldw_mx", C.c_int64), ("w_mxs", C.c_void_p), ("ldw_s", C.c_int64),
+        ("out_mxs", C.c_void_p), ("ldo_s", C.c_int64), ("ldol", C.c_int64), ("ldrl", C.c_int64),
     ]
 
 
@@ -157,6 +161,85 @@ class H2IL:
         return self.planes().float()
 
 
+def mx_scale_pitch(C_: int) -> int:
+    """Bytes per scale plane and row of an mx operand with C_ columns (include/cvlm.h ABI 10): one byte per 64-column group, padded to
+    whole dwords (the kernel reads the bytes of four groups at once)."""
+    return (C_ // 64 + 3) // 4 * 4
+
+
+def mx_pack(x: "H2"):
+    """h2 planes [2][R][C] (C % 64 == 0) -> (image uint8 [R][C / 64][256], scales uint8 [R][4][mx_scale_pitch(C)]) of include/cvlm.h
+    ABI 10, in torch (weights at load time; the reference the tests hold the GEMM epilogue's own mx output against, bit for bit):
+    per 32 columns E = max(exponent field of the largest |hi| as f32, 103) - 7, hi8 = e4m3(hi / 2^(E - 127)), lo8 = e4m3(lo / 2^(E - 138))."""
+    two, R, C_ = x.t.shape
+    assert two == 2 and C_ % 64 == 0
+    hi, lo = x.t[0], x.t[1]
+    hf = hi.float()
+    bmax = hf.abs().view(R, C_ // 32, 32).amax(-1)
+    ex = ((bmax.view(torch.int32) >> 23) & 0xff).clamp_min(103) - 7                      # [R][C / 32]
+    s_hi = (ex << 23).view(torch.float32)
+    s_lo = ((ex - 11) << 23).view(torch.float32)
+    hi8 = (hf.view(R, C_ // 32, 32) / s_hi[..., None]).to(torch.float8_e4m3fn).view(torch.uint8).view(R, C_ // 64, 64)
+    lo8 = (lo.float().view(R, C_ // 32, 32) / s_lo[..., None]).to(torch.float8_e4m3fn).view(torch.uint8).view(R, C_ // 64, 64)
+    img = torch.cat([hi.contiguous().view(torch.uint8).view(R, C_ // 64, 128), hi8, lo8], dim=2).contiguous()
+    su = mx_scale_pitch(C_)
+    sc = torch.zeros(R, 4, su, dtype=torch.uint8, device=x.t.device)
+    e2 = ex.view(R, C_ // 64, 2).to(torch.uint8)
+    sc[:, 0, :C_ // 64], sc[:, 1, :C_ // 64] = e2[:, :, 0], e2[:, :, 1]
+    sc[:, 2, :C_ // 64], sc[:, 3, :C_ // 64] = e2[:, :, 0] - 11, e2[:, :, 1] - 11
+    return img, sc
+
+
+class H2MX:
+    """Split-half activation as an mx operand (include/cvlm.h ABI 10): `t` uint8 [M][4 * C] -- per 64 columns 128 bytes of fp16 hi, 64
+    of e4m3 hi8, 64 of e4m3 lo8 --, `s` uint8 [M][4][pitch] the block exponents, `lo` (optional) the fp16 lo PLANE [M][C] kept beside
+    the image where a later launch reads the tensor as its h2 residual.  Written by cvlm_gemm (out_mx), read by it (a_mx / res_mx)."""
+
+    __slots__ = ("t", "s", "lo", "C", "c0")
+    mx = True
+
+    def __init__(self, t: torch.Tensor, s: torch.Tensor, lo: Optional[torch.Tensor], C_: int, c0: int = 0):
+        assert t.dtype == torch.uint8 and t.dim() == 2 and s.dtype == torch.uint8 and s.dim() == 3 and s.shape[1] == 4
+        self.t, self.s, self.lo, self.C, self.c0 = t, s, lo, C_, c0
+
+    @staticmethod
+    def empty(M: int, C_: int, device="cuda", lo_plane: bool = False) -> "H2MX":
+        assert C_ % 64 == 0
+        return H2MX(torch.empty(M, 4 * C_, dtype=torch.uint8, device=device),
+                    torch.zeros(M, 4, mx_scale_pitch(C_), dtype=torch.uint8, device=device),
+                    torch.empty(M, C_, dtype=torch.float16, device=device) if lo_plane else None, C_)
+
+    @staticmethod
+    def from_planes(x: "H2", lo_plane: bool = False) -> "H2MX":
+        img, sc = mx_pack(x)
+        return H2MX(img.view(img.shape[0], -1), sc, x.t[1].contiguous() if lo_plane else None, x.t.shape[2])
+
+    def cols(self, c0: int) -> "H2MX":
+        """The operand that starts at column c0 (c0 % 64 == 0): same rows, same pitches."""
+        assert c0 % 64 == 0 and self.lo is None
+        return H2MX(self.t, self.s, None, self.C - c0, self.c0 + c0)
+
+    def data_ptr(self) -> int:
+        return self.t.data_ptr() + 4 * self.c0
+
+    def scale_ptr(self) -> int:
+        return self.s.data_ptr() + self.c0 // 64
+
+    def hi(self) -> torch.Tensor:
+        M = self.t.shape[0]
+        return self.t.view(M, -1, 256)[:, :, :128].contiguous().view(torch.float16).view(M, -1)[:, self.c0:self.c0 + self.C]
+
+    def planes8(self):
+        """(hi8, lo8) decoded to f32 [M][C]: what the fp8 products multiply."""
+        M = self.t.shape[0]
+        g = self.t.view(M, -1, 256)
+        n = g.shape[1]
+        e = self.s[:, :, :n].permute(0, 2, 1).float()                                     # [M][groups][4]
+        dec = lambda b, pl: (b.contiguous().view(torch.float8_e4m3fn).float().view(M, n, 2, 32) *
+                             torch.exp2(e[:, :, pl:pl + 2] - 127.0)[..., None]).view(M, -1)[:, self.c0:self.c0 + self.C]
+        return dec(g[:, :, 128:192], 0), dec(g[:, :, 192:256], 2)
+
+
 def interleave_planes(w: "H2") -> torch.Tensor:
     """[2][N][K] planes -> fp16 [N][2K] with row n = (hi k0..31 | lo k0..31 | hi k32..63 | lo k32..63 | ...): the `w_il` image of
     cvlm_gemm (include/cvlm.h, ABI 6).  K % 32 == 0."""
@@ -220,8 +303,10 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          ln_fold: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          residual_h2: Optional[Tuple["H2", float]] = None, ldrh: Optional[int] = None,
          row_stats: Optional[torch.Tensor] = None, conv3x3: Optional[Tuple[int, int, int]] = None,
-         w_il: Optional[torch.Tensor] = None) -> None:
-    """w_il: the same weight with its planes interleaved per 32 k-elements (`interleave_planes(w)`, ABI 6): the big-tile kernels stage
+         w_il: Optional[torch.Tensor] = None, w_mx: Optional["H2MX"] = None) -> None:
+    """w_mx: the weight as an mx operand (`H2MX.from_planes(w)`, ABI 10) -- used when `a` is an H2MX: hi.hi on fp16, the two correction
+    products on the block-scaled e4m3 matrix instruction.  An H2MX `out_h2` / `residual_h2` selects out_mx / res_mx.
+    w_il: the same weight with its planes interleaved per 32 k-elements (`interleave_planes(w)`, ABI 6): the big-tile kernels stage
     the weight from it (whole 128-byte lines per row and K-tile), same bits.
     conv3x3 = (H, W, C): `a` is an NHWC image [B*H*W][C] and K = 9*C runs over the taps of a 3x3 / pad 1 convolution
     (implicit GEMM: the im2col gather happens in the DMA addresses).
@@ -231,7 +316,12 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     (plain stores, bit-reproducible: nothing to zero)."""
     _on_current_device(a.t)
     g = GemmArgs()
-    if getattr(a, "il", False):
+    if getattr(a, "mx", False):
+        assert w_mx is not None and w_mx.C >= K and a.C >= K, "an mx activation needs the mx image of the weight"
+        g.a_hi, g.a_lo, g.lda, g.stride_a, g.a_mx = a.data_ptr(), 0, a.t.stride(0) // 2, 0, 1
+        g.a_mxs, g.lda_s = a.scale_ptr(), a.s.stride(1)
+        g.w_mx, g.ldw_mx, g.w_mxs, g.ldw_s = w_mx.data_ptr(), w_mx.t.stride(0) // 2, w_mx.scale_ptr(), w_mx.s.stride(1)
+    elif getattr(a, "il", False):
         g.a_hi, g.a_lo, g.lda, g.stride_a, g.a_il = a.t.data_ptr(), 0, a.t.stride(0), 0, 1
     else:
         g.a_hi, g.a_lo, g.lda, g.stride_a = a.hi.data_ptr(), a.lo.data_ptr(), lda if lda is not None else K, stride_a
@@ -243,7 +333,12 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     g.residual, g.ldr, g.stride_r = _p(residual), (ldr if ldr is not None else N), stride_r
     g.out_f32, g.ldo, g.stride_o = _p(out_f32), (ldo if ldo is not None else N), stride_o
     g.ldoh, g.stride_oh = (ldoh if ldoh is not None else N), stride_oh
-    if out_h2 is not None and getattr(out_h2, "il", False):
+    if out_h2 is not None and getattr(out_h2, "mx", False):
+        g.out_hi, g.ldoh, g.out_mx = out_h2.data_ptr(), out_h2.t.stride(0) // 2, 1
+        g.out_mxs, g.ldo_s = out_h2.scale_ptr(), out_h2.s.stride(1)
+        if out_h2.lo is not None:
+            g.out_lo, g.ldol = out_h2.lo.data_ptr(), out_h2.lo.stride(0)
+    elif out_h2 is not None and getattr(out_h2, "il", False):
         g.out_hi, g.out_lo, g.ldoh, g.out_il = out_h2.t.data_ptr(), 0, out_h2.t.stride(0), 1
     elif out_h2 is not None:
         g.out_hi, g.out_lo = out_h2.hi.data_ptr(), out_h2.lo.data_ptr()
@@ -259,7 +354,11 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
         g.ln_stats, g.ln_colsum = ln_fold[0].data_ptr(), ln_fold[1].data_ptr()
     if residual_h2 is not None:
         r, rs = residual_h2
-        if getattr(r, "il", False):
+        if getattr(r, "mx", False):
+            assert r.lo is not None, "an mx residual needs its fp16 lo plane"
+            g.res_hi, g.res_lo, g.ldrh, g.res_scale, g.res_mx = r.data_ptr(), r.lo.data_ptr(), r.t.stride(0) // 2, rs, 1
+            g.ldrl = r.lo.stride(0)
+        elif getattr(r, "il", False):
             g.res_hi, g.res_lo, g.ldrh, g.res_scale, g.res_il = r.t.data_ptr(), 0, r.t.stride(0), rs, 1
         else:
             g.res_hi, g.res_lo, g.ldrh, g.res_scale = r.hi.data_ptr(), r.lo.data_ptr(), (ldrh if ldrh is not None else N), rs

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 9
+#define CVLM_ABI_VERSION 10
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -110,6 +110,28 @@ typedef struct cvlm_gemm_args {
      *   res_il: res_hi is such an image (res_lo unused), ldrh its row stride
      * A column offset c0 (c0 % 32 == 0) into an image is the pointer offset 2 * c0 halves. */
     int32_t a_il, out_il, res_il;
+    /* ABI 10 -- `mx` operands: the two CORRECTION products of the split (lo.hi and hi.lo, each 2^-11 of hi.hi) on gfx950's block-scaled
+     * fp8 matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 operands: twice the fp16 rate, ~2.1 x the flops per joule), the
+     * main product hi.hi on fp16 as before:  acc += Whi.Ahi + Whi8.Alo8 + Wlo8.Ahi8, fp32 accumulation.  The corrections need ~5
+     * significant bits for a 2^-16 product; measured on the reference's outputs at the demo geometry (tools/precision_emulate.py,
+     * profiles/r05_precision_emulation.log): mask 1.3e-4 / IoU 0.99998 with qkv, lin1 and lin2 of all 32 ViT-H blocks in this form
+     * (3 x fp16: 4e-5; fp16 alone: 1.5e-2; gate 1e-3).
+     * An mx operand is an IMAGE plus a SCALE array, both derived from the h2 planes (hi, lo) of the same values:
+     *   image   uint8 t[r][c / 64][256]  bytes 0-127: fp16 hi of the group's 64 columns; 128-191: hi8 (e4m3) of the same; 192-255: lo8
+     *           (row stride given in HALVES like the *_il images, >= 2 * C; a column offset c0, c0 % 64 == 0, is 2 * c0 halves)
+     *   scales  uint8 s[r][4][ld_s]      plane 0 / 1: exponent E (E8M0, value 2^(E - 127)) of hi8 for columns 0-31 / 32-63 of group u
+     *           (byte u), plane 2 / 3: the same for lo8 (E - 11).  E = exponent field of the largest |hi| of the 32 columns as an f32,
+     *           at least 103, minus 7;  hi8 = e4m3_rne(hi / 2^(E - 127)),  lo8 = e4m3_rne(lo / 2^(E - 138)).  ld_s % 4 == 0, >= C / 64.
+     *   a_mx:   a_hi = image (lda its row stride), a_mxs / lda_s = scales; needs w_mx; K % 64 == 0.  Served by the 256 x 256 kernel.
+     *   w_mx / ldw_mx, w_mxs / ldw_s: the weight in the same form.
+     *   out_mx: out_hi = image (ldoh), out_mxs / ldo_s = scales; out_lo, when given, receives the fp16 lo PLANE [M][ldol] (what a later
+     *           launch reads as the lo half of its h2 residual: the residual stream keeps its 22 bits).  LDS-staged epilogues, N % 64 == 0
+     *           at 64-aligned columns, not head-major.
+     *   res_mx: res_hi = image (ldrh; its hi halves are read), res_lo = fp16 lo plane [M][ldrl]. */
+    int32_t a_mx, out_mx, res_mx;
+    const void* a_mxs; int64_t lda_s;
+    const void* w_mx; int64_t ldw_mx; const void* w_mxs; int64_t ldw_s;
+    void* out_mxs; int64_t ldo_s; int64_t ldol; int64_t ldrl;
 } cvlm_gemm_args;
 int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
 int64_t cvlm_gemm_workspace_bytes(void);

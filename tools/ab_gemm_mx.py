@@ -1,0 +1,66 @@
+"""A/B of the mx operand form against the split-3 form of the same launch (include/cvlm.h ABI 10), alternating inside one process:
+the three ViT-H block GEMMs that run on mx operands (qkv: LayerNorm fold, head-major store; lin1: LayerNorm fold + GELU, mx out;
+lin2: h2 residual + row statistics, mx out + lo plane), at B = 8 (M = 32768) or SHAPES=b1 (M = 4096) / clip2 (c_proj of the fused
+CLIP forward).  Prints microseconds per launch and algorithmic TFLOP/s.
+    python tools/ab_gemm_mx.py            # PROBE=1: launches of the probe library named by CVLM_PROBE_LIB instead
+"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from camouflaged_vlm_amd import hip as H
+H.load()
+dev = "cuda"
+M = {"b1": 4096}.get(os.environ.get("SHAPES", ""), 32768)
+shapes = [("qkv", M, 3840, 1280, "fold_hm"), ("lin1", M, 5120, 1280, "fold_gelu"), ("lin2", M, 1280, 5184, "h2res")]
+if os.environ.get("SHAPES") == "clip2":
+    shapes = [("clip pj", 9296, 1024, 4096, "h2res")]
+ws = H.new_gemm_workspace(dev)
+REPS, INNER = int(os.environ.get("REPS", "3")), int(os.environ.get("INNER", "10"))
+for name, M, N, K, form in shapes:
+    torch.manual_seed(0)
+    ap = H.H2(torch.stack([(torch.randn(M, K) * 0.25).half(), (torch.randn(M, K) * 1e-4).half()]))
+    wp = H.H2(torch.stack([(torch.randn(N, K) * 0.5).half(), (torch.randn(N, K) * 2e-4).half()]))
+    A_il, A_mx = H.H2IL.from_planes(H.H2(ap.t.to(dev))), H.H2MX.from_planes(ap)
+    A_mx = H.H2MX(A_mx.t.to(dev), A_mx.s.to(dev), None, A_mx.C)
+    W = H.H2(wp.t.to(dev))
+    W_il = H.interleave_planes(W)
+    W_mx = H.H2MX.from_planes(wp)
+    W_mx = H.H2MX(W_mx.t.to(dev), W_mx.s.to(dev), None, W_mx.C)
+    bias = torch.randn(N, device=dev)
+    kw = dict(bias=bias, workspace=ws, w_il=W_il)
+    if form.startswith("fold"):
+        merged = torch.stack([torch.rand(M, device=dev) + 0.5, torch.randn(M, device=dev) * 0.01], 1).contiguous()
+        kw.update(ln_fold=(merged, torch.randn(N, device=dev)))
+    if form == "fold_hm":
+        kw.update(head_major=(4096, 16, 80))
+        outs = {"split3": H.H2.empty(M, N, device=dev), "mx": H.H2.empty(M, N, device=dev)}
+    elif form == "fold_gelu":
+        kw.update(act=H.ACT_GELU, out_scale=0.25)
+        outs = {"split3": H.H2IL.empty(M, N, device=dev), "mx": H.H2MX.empty(M, N, device=dev)}
+    else:
+        r_il = H.H2IL.from_planes(H.H2(torch.randn(2, M, N, device=dev).half()))
+        r_mx = H.H2MX.empty(M, N, device=dev, lo_plane=True)
+        r_mx.t.copy_(H.H2MX.from_planes(H.H2(torch.randn(2, M, N).half())).t)
+        r_mx.lo.normal_()
+        stats = torch.zeros(H.stats_pieces(N), M, 2, device=dev)
+        kw.update(row_stats=stats)
+        outs = {"split3": r_il, "mx": r_mx}
+    res = {"split3": [], "mx": []}
+    for rep in range(REPS):
+        for mode in ("split3", "mx"):
+            a = A_il if mode == "split3" else A_mx
+            k2 = dict(kw)
+            if mode == "mx":
+                k2["w_mx"] = W_mx
+            if form == "h2res":
+                k2["residual_h2"] = (outs[mode], 1.0)
+            H.gemm(a, W, M, N, K, out_h2=outs[mode], **k2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(INNER):
+                H.gemm(a, W, M, N, K, out_h2=outs[mode], **k2)
+            e1.record(); torch.cuda.synchronize()
+            res[mode].append(e0.elapsed_time(e1) * 1e3 / INNER)
+    fl = 2.0 * M * N * K
+    print(f"{name:8s} {M}x{N}x{K} " + "  ".join(f"{m}: {min(r):7.1f} us = {fl / min(r) / 1e6:5.0f} TF/s" for m, r in res.items()) +
+          f"   ({min(res['split3']) / min(res['mx']):.3f} x)", flush=True)
+assert H.gemm_workspace_errors(ws) == 0

@@ -24,7 +24,7 @@ time.sleep(1.5)
 t0 = time.time(); time.sleep(2.5); print("idle:", window(t0 - 1.0, time.time() + 0.2), flush=True)
 binp = os.path.join(ROOT, "tools", "micro", "bin", "mfma_power")
 if os.path.exists(binp):
-    order_study = os.environ.get("MFMA_ORDER") in ("1", "2")  # operand reuse between consecutive MFMAs only (mfma_power.hip k_order / k_gemm)
+    order_study = os.environ.get("MFMA_ORDER") in ("1", "2", "3", "4")  # operand reuse between consecutive MFMAs only (mfma_power.hip k_order / k_gemm)
     out = subprocess.run([binp, "4"] + ([os.environ["MFMA_ORDER"]] if order_study else []), capture_output=True, text=True).stdout
     for line in out.splitlines():
         m = re.search(r"t0 ([0-9.]+) t1 ([0-9.]+)", line)
