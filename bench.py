@@ -54,7 +54,7 @@ ENCODER_TFLOP_PER_IMAGE = {1024: 5.681, 1536: 13.712}
 # Measured on this part (tools/power_roofline.py, profiles/r02_power_roofline.log): an MFMA-only loop (16x16x32 f16, random
 # operands, every CU) settles at 1.88 PF at the 1400-W socket cap (sclk 1.95 GHz of 2.4): what the matrix pipe can sustain.
 MFMA_F16_POWER_ROOFLINE_TFLOPS = 1880.0
-TRAFFIC_FILES = ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest first
+TRAFFIC_FILES = {"mx": ("r05_gemm_traffic.json",), "exact": ("r05_gemm_traffic_exact.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")}   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest first
 
 
 def under_profiler() -> bool:
@@ -196,7 +196,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "exact"), choices=["exact", "mx", "mixed", "fast"])
+    ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "mx"), choices=["mx", "exact", "mixed", "fast"])
     ap.add_argument("--geometry", default="demo", choices=["demo", "tiny", "hires1536"])
     ap.add_argument("--workload", default="cascade", choices=["cascade", "encoder"],
                     help="encoder = SAM ViT-H image encoder only (BASELINE configs[1] / [4] with --geometry hires1536)")
@@ -324,7 +324,7 @@ class Roofline:
             nb = kw.get("batch", 1)
             by = 4.0 * (M * K + N * K) * nb + (4.0 * M * N * nb if (kw.get("residual") is not None or kw.get("residual_h2") is not None) else 0.0) \
                 + 4.0 * M * N * nb * ((kw.get("out_f32") is not None) + (kw.get("out_h2") is not None))
-            records.append((2.0 * M * N * K * nb, e0, e1, by))
+            records.append((2.0 * M * N * K * nb, e0, e1, by, bool(getattr(a, "mx", False))))
 
         def timed_attn(qkv, o, Bn, S, heads, hd, **kw):
             mode = kw.get("mode", 0)
@@ -350,10 +350,10 @@ class Roofline:
         self.hip.gemm, self.hip.attention = self.orig, self.orig_attn
         return False
 
-    def result(self, nrep: int, step_seconds: float, traffic_ok: bool) -> dict:
+    def result(self, nrep: int, step_seconds: float, traffic_ok: bool, precision: str = "exact") -> dict:
         records, arecs = self.records, self.arecs
         traffic, tnote = None, None
-        for tname in TRAFFIC_FILES:
+        for tname in TRAFFIC_FILES.get(precision, ()):
             tfile = os.path.join(REPO, "profiles", tname)
             if traffic_ok and os.path.exists(tfile):
                 with open(tfile) as f:
@@ -384,7 +384,16 @@ class Roofline:
                               "algorithmic_gflop_per_launch": round(f_ / len(rs) / 1e9, 3),
                               "note": "achieved / frac: algorithmic FLOPs (4*S^2*hd per head, SURVEY.md §8d); issued: the MFMA flops the "
                                       "exact mode executes for them (3 f16 products per multiply; round 2 also padded head dim 80 to 96 in P.V)"})
-        return {"kernel": "gemm_nt_kernel<split=%d>" % self.split, "bound": "mfma",
+        mx_flops = sum(r[0] for r in records if r[4])
+        mx_ms = sum(r[1].elapsed_time(r[2]) for r in records if r[4])
+        # matrix-pipe work in f16-MFMA equivalents: a split-3 launch issues 3 f16 products per multiply, an mx launch 1 f16 product + 2 e4m3
+        # products at twice the f16 rate (= 2 equivalents)
+        issued_factor = (3.0 * (flops - mx_flops) + 2.0 * mx_flops) / flops if self.split == 3 else float(self.split)
+        kname = "gemm_nt_kernel<split=%d>" % self.split
+        if mx_flops > 0:
+            kname = ("gemm_nt_kernel: mx unit form (f16 hi.hi + block-scaled e4m3 corrections; %.0f %% of the GEMM flops, %.0f TFLOP/s algorithmic "
+                     "on its own) + split-3 forms elsewhere" % (100.0 * mx_flops / flops, mx_flops / (mx_ms * 1e-3) / 1e12))
+        return {"kernel": kname, "bound": "mfma",
                 "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": tnote,
                 "algorithmic_bytes_per_launch": round(abytes / len(records)),
@@ -396,10 +405,11 @@ class Roofline:
                 "launches": len(records), "avg_launch_us": round(1e3 * ms / len(records), 2),
                 "algorithmic_gflop_per_launch": round(flops / len(records) / 1e9, 3),
                 "gemm_share_of_step": round(ms * 1e-3 / nrep / step_seconds, 3),
-                "issued": round(achieved * self.split, 2),
-                "issued_note": "MFMA flops issued: the exact mode forms every product from 3 f16 MFMAs (hi.hi + lo.hi + hi.lo)",
+                "issued": round(achieved * issued_factor, 2),
+                "issued_note": "matrix-pipe work in f16-MFMA equivalents: split-3 launches form every product from 3 f16 MFMAs (hi.hi + lo.hi + "
+                               "hi.lo), mx launches from 1 f16 MFMA + 2 e4m3 MFMAs at twice the f16 rate (= 2)",
                 "power_roofline": {"peak": MFMA_F16_POWER_ROOFLINE_TFLOPS, "unit": "TFLOP/s issued",
-                                   "frac_issued": round(achieved * self.split / MFMA_F16_POWER_ROOFLINE_TFLOPS, 4),
+                                   "frac_issued": round(achieved * issued_factor / MFMA_F16_POWER_ROOFLINE_TFLOPS, 4),
                                    "note": "what an MFMA-only loop sustains at the 1400-W socket cap with random operands "
                                            "(profiles/r02_power_roofline.log); the GEMM itself runs AT the cap: its energy per "
                                            "launch = matrix pipe 51 % + L2->LDS DMA 26 % + idle 21 % (DESIGN.md section 6)"},
@@ -501,6 +511,9 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
     # pipelined: stage 2 shares one CLIP forward with the next batch's pass 1 -- other K-splits, other fp32 summation order: a mask level
     # may move on a handful of pixels
     parity["ok"] = bool(finite and handoff == 0 and (same_run is None or same_run < (1e-4 if args.pipelined else 1e-12)))
+    # with --no-cpu-baseline nothing below compares against the oracle; `ok` is then self-consistency only and says so
+    parity["ok_means"] = "self-consistency only (finite outputs, no hand-off errors, the timed loop's dict equals the first pass): nothing was " \
+                         "compared with the oracle / reference in this run"
 
     # ---- cpu_baseline leg: the same loop's two tails as the reference runs them, on the host -- Pillow + numpy preprocessing (what
     # torchvision's transforms call, datasets/wrappers.py:22-62) and D2H + cv2-style resize + the six numpy metric classes
@@ -577,6 +590,7 @@ def evalloop_line(args, torch, np, g, c, dev, B, make_model, sampler, t0, percen
                                     "tests/golden/evaltail.npz); cv2.resize restated, unpinned"})
         parity["ok"] = bool(parity["ok"] and err_a <= 1e-9 and err_b <= 1e-4 and worst_levels <= 1 and frac_moved < 1e-3 and cls_err < 1e-9 and
                             cls_ok and n1_equal and cod_err <= 1e-5)
+        parity["ok_means"] = "checked against the oracle (the reference's metric classes, pinned) as listed"
         n1_ms, n2_ms = 1e3 * sum(t_n1) / n_all, 1e3 * sum(t_n2) / n_all
         gpu_path_ms = per_img["path_infer_test_stage2"]
         cpu = {"value": round(1e3 / (gpu_path_ms + n1_ms + n2_ms), 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -959,17 +973,24 @@ def main():
     # shared text-embedding bank: sharded over ranks + all-gathered (the only collective on the path)
     tt = time.time()
     tf = gather_text_features(cas.clip, eot, "test")
+    # SURVEY.md §8(e) / BASELINE configs[2] "75 OVCamo class prompts": the 14 TRAIN prompts travel the same way (their bank is what
+    # CustomCLIP.forward(train=True) scores against, cocotrainers/mapleAlphaCLIP.py:267-280); the timed inference path reads the 61 test rows
+    eot_tr = host.eot_for_classes(host.ovcamo_constants()["names_train"].tolist())[:c.n_cls_train] \
+        if args.geometry == "demo" else spec.default_eot(c, "train")
+    tf_tr = gather_text_features(cas.clip, eot_tr, "train")
     torch.cuda.synchronize()
     text_bank_s = time.time() - tt
     bank_check = None
     if world > 1:
-        # the gathered bank is bit-identical on every rank and equal to the single-GPU bank
-        alone = cas.clip.text_features(eot, "test")
-        same = torch.tensor([int(torch.equal(alone, tf))], device=dev)
+        # the gathered banks are bit-identical on every rank and equal to the single-GPU banks
+        alone, alone_tr = cas.clip.text_features(eot, "test"), cas.clip.text_features(eot_tr, "train")
+        same = torch.tensor([int(torch.equal(alone, tf) and torch.equal(alone_tr, tf_tr))], device=dev)
         dist.all_reduce(same, op=dist.ReduceOp.MIN)
         bank_check = {"bit_identical_to_single_rank_bank_on_every_rank": bool(int(same.item())),
-                      "max_abs_diff_rank0": float((alone - tf).abs().max())}
+                      "rows_gathered": {"test": int(tf.shape[0]), "train": int(tf_tr.shape[0])},
+                      "max_abs_diff_rank0": float(max((alone - tf).abs().max(), (alone_tr - tf_tr).abs().max()))}
     cas.clip.set_text_bank(tf, bank, "test")
+    cas.clip.set_text_bank(tf_tr, torch.from_numpy(host.ovcamo_constants()["bank_train"][:c.n_cls_train]).float(), "train")
     setup_s = time.time() - t0
 
     def step(k):
@@ -1024,7 +1045,7 @@ def main():
         finally:
             cas.overlap_clip = was_overlap
         roofline = rf.result(nrep, mine / args.steps,
-                             traffic_ok=(args.geometry == "demo" and args.precision == "exact" and B == 8))
+                             traffic_ok=(args.geometry == "demo" and args.precision in ("mx", "exact") and B == 8), precision=args.precision)
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N = 1)
     cpu = None

@@ -393,8 +393,11 @@ int launch_split(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-int cvlm_attention_global64(const cvlm_attn_args& g, hipStream_t s);       // attention_g64.hip
-int cvlm_attention_window14(const cvlm_attn_args& g, hipStream_t s);       // attention_win.hip
+// The two ViT-H kernels of the parity mode (split 3 on both products): every other precision, window size and map size runs the
+// generic kernel of this file.  (Rounds 1-4 also built a single-group global kernel and a two-workgroups-per-pair window kernel for
+// the non-parity precisions: they carried no headline and left the build in round 5.)
+int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s);    // attention_g64pp.hip: 64 x 64 and 96 x 96 maps
+int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s);    // attention_win2.hip: 14 x 14 windows, h2 output
 
 int64_t cvlm_attention_global64_pp_workspace_bytes(const cvlm_attn_args& g);   // attention_g64pp.hip
 
@@ -421,16 +424,16 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!g.relh_hi || !g.relw_hi || (g.split_qk == 3 && (!g.relh_lo || !g.relw_lo))) return CVLM_E_BADARG;
     if (g.grid <= 0 || g.S != g.grid * g.grid) return CVLM_E_BADARG;
     if (g.mode == 1) {
-        if (g.grid == 64 || g.grid == 96) {                                    // 1024^2 / 1536^2 SAM geometries: fast paths
-            const int rc = cvlm_attention_global64(g, s);
-            if (rc != CVLM_E_UNSUPPORTED) return rc;
+        if ((g.grid == 64 || g.grid == 96) && g.split_qk == 3 && g.split_pv == 3) {   // 1024^2 / 1536^2 SAM geometries, parity mode
+            const int rc = cvlm_attention_global64_pp(g, s);
+            if (rc != CVLM_E_UNSUPPORTED) return rc;                           // incl. CVLM_E_WORKSPACE: a missing workspace is an error, not a silent fallback
         }
         p.L = g.grid; p.LTP = g.grid | 1;
         return launch_split<80, 4, 1, false>(p, s);
     }
     if (g.mode == 2) {
         if (g.window <= 0 || !g.pad_hi || ((g.split_qk == 3 || g.split_pv == 3) && !g.pad_lo)) return CVLM_E_BADARG;
-        if (g.window == 14) return cvlm_attention_window14(g, s);             // SAM window geometry fast path
+        if (g.window == 14 && g.split_qk == 3 && g.split_pv == 3 && g.out_lo) return cvlm_attention_window14_pc(g, s);   // SAM window geometry, parity mode
         p.L = g.window; p.LTP = g.window | 1;
         p.nwx = (g.grid + g.window - 1) / g.window;
         p.S_seq = g.window * g.window;

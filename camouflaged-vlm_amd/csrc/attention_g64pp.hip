@@ -1,6 +1,6 @@
 // ViT-H *global* attention on the 64x64 token map, ping-pong schedule (exact mode: hi/lo operands on both GEMMs).
-// Same mathematics and operand layouts as attention_g64.hip (query on the lane for S^T = K.Q^T and O^T = V^T.P^T,
-// rel-pos bias = Th[q][kh] from LDS + Tw[q][kw] from 32 registers); what changes is WHO runs WHEN:
+// Query on the lane for S^T = K.Q^T and O^T = V^T.P^T (the layouts of the single-group kernel of rounds 1-4, which left the build in round 5;
+// rel-pos bias = Th[q][kh] from LDS + Tw[q][kw] from 32 registers); what this form changed is WHO runs WHEN:
 //
 //   * one workgroup of 8 waves per 256 queries; waves w and w + 4 share a SIMD.  A key tile costs a wave two phases,
 //         X(t): softmax of S(t)                      -- VALU / transcendental only

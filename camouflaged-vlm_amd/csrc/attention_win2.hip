@@ -1,14 +1,20 @@
 // ViT-H *window* attention (14x14 windows, head_dim 80, exact mode), producer / consumer form (round 3).
-// image_encoder.py:488-504, 507-553, 589-625; the same mathematics and fragment layouts as attention_win.hip
-// (query on the lane for S^T and O^T, rel-pos bias folded into the QK^T contraction through an augmented k-step pair,
-// pad tokens = qkv bias rows read by source address), a different division of labour:
+// image_encoder.py:488-504, 507-553, 589-625.  Query on the lane for S^T and O^T; pad tokens = qkv bias rows read by source
+// address, never stored.  The rel-pos bias is folded into the QK^T contraction instead of being gathered per score element:
+//     Q_aug = [ q (80) | Th[q][0..13]/scale | Tw[q][0..13]/scale | 0 0 0 0 ]      (112 = 7 k-steps of 16)
+//     K_aug = [ k (80) | onehot14(kh)       | onehot14(kw)       | 0 0 0 0 ]
+// so S^T = K_aug . Q_aug^T already contains (q.k + bias/scale).  The one-hot block is the same for every window and head: a
+// 224 x 32 constant image in the code object, copied to LDS by 14 DMA instructions; Th / Tw are formed once per pair with MFMA
+// (U = Q . R^T, 27 table rows).  (Rounds 1-4 also carried the kernel this one replaced -- two 4-wave workgroups per (window,
+// head) pair, each streaming all keys and issuing its own DMA: "the older form" below; it served the non-parity precisions and
+// left the build in round 5, which now take the generic kernel of attention.hip.)  Division of labour:
 //
 //   * ONE workgroup per CU, persistent over a list of (window, head) pairs; 8 waves:
 //       waves 0..6  CONSUMERS, 32 query slots each = 224 >= 196 queries of the pair: K / V tiles are read ONCE per pair
-//                   (attention_win.hip runs two 4-wave workgroups per pair, each streaming all keys);
+//                   (the older form ran two 4-wave workgroups per pair, each streaming all keys);
 //       wave  7     PRODUCER: issues every LDS-DMA instruction of the workgroup -- rel-pos tables and one-hot block once, then
 //                   the K / V tiles of pair after pair as one endless stream of 32-key tiles, two tiles ahead of the consumers.
-//     In attention_win.hip a third of a tile's time goes into ISSUING the five DMA instructions a wave owes per tile (row-offset
+//     In the older form a third of a tile's time went into ISSUING the five DMA instructions a wave owes per tile (row-offset
 //     reads, 64-bit address arithmetic, m0 set-up, ~125 ns each), and the first tiles of a workgroup land while it waits: here
 //     the consumers issue no vector-memory instruction inside the key loop at all, and the first tiles of pair n + 1 arrive
 //     under the last tiles of pair n (the producer does not know item boundaries, only tile numbers).
@@ -44,7 +50,7 @@ __device__ __forceinline__ void step_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// one-hot block of K_aug (see attention_win.hip): row = key slot, 32 columns = onehot14(kh) | 0 0 | onehot14(kw) | 0 0,
+// one-hot block of K_aug (file header): row = key slot, 32 columns = onehot14(kh) | 0 0 | onehot14(kw) | 0 0,
 // the four 16-byte chunks of a row stored at chunk ^ ((row >> 2) & 3)
 struct OneHotImage2 { half_t v[224 * 32]; };
 constexpr OneHotImage2 make_onehot_image2() {

@@ -429,19 +429,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             __builtin_amdgcn_s_barrier();
         }
     } else if constexpr (NSTAGE == 5 && MX) {
-        // The staggered two-slot loop of the branch below over UNITS (see the template comment): even units multiply fp16 lines, odd
-        // units e4m3 lines; eight units (four unit pairs = the four scale bytes of one dword) are one pass of the loop body.
+        // UNITS: one 128-byte line per row -- even units fp16 lines (k 0-31 | k 32-63 of hi), odd units e4m3 lines (hi8 k 0-63 | lo8 k 0-63)
+        // of the same 64 k-elements; eight units (four unit pairs = the four scale bytes of one dword) are one pass of the loop body.
         //   fragment registers: wf[i] = (chunk fq | chunk 4 + fq) of weight rows, af[i] = (chunk 4 + fq | chunk fq) of activation rows
         //   f16 unit : chunk c of a line = k 8c .. 8c + 7:  acc += W(chunk fq) . A(chunk fq) + W(chunk 4 + fq) . A(chunk 4 + fq)
-        //   fp8 unit : line = (hi8 k 0-63 | lo8 k 0-63).  The instruction's lane (r, q) supplies k' = 16q .. 16q + 15 with its first 16
-        //              bytes and k' = 64 + 16q .. with its second 16 (tools/micro/mx_semantics.hip, measured), so with the registers
-        //              above its K = 128 is [Whi8 (k 0-63) | Wlo8 (k 0-63)] . [Alo8 (k 0-63) | Ahi8 (k 0-63)]: both corrections.
+        //   fp8 unit : the instruction's lane (r, q) supplies k' = 16q .. 16q + 15 with its first 16 bytes and k' = 64 + 16q .. with its
+        //              second 16 (tools/micro/mx_semantics.hip, measured), so with the registers above its K = 128 is
+        //              [Whi8 (k 0-63) | Wlo8 (k 0-63)] . [Alo8 (k 0-63) | Ahi8 (k 0-63)]: both corrections in one instruction.
         //   scales   : the E8M0 byte of k'-block b (32 elements) comes from lane (r, b): weight lanes read scale plane fq (hi8 first),
         //              activation lanes plane fq ^ 2 (lo8 first); one dword = the bytes of four unit pairs, op_sel picks the pair.
+        // RING.  With a third fewer matrix cycles per k the two-slot loop below stops hiding the operand stream: a unit's DMA (64 KiB per
+        // CU) needs ~1.3 us to land when every CU streams (profiles/r05_gemm_mx_probes.log: the DMA skeleton alone 534 us of a 700-us
+        // launch, the multiplies without DMA 545), and the staggered two-slot schedule gives a piece half a unit to a unit.  Here the
+        // 160 KiB hold FIVE half-slots of 32 KiB -- the 256 activation rows or the 256 weight rows of one unit; unit u lives in
+        // half-slots (2u) % 5 and (2u + 1) % 5 -- and ONE barrier per unit: behind barrier t (unit t + 1 has landed, unit t's
+        // half-slots are free) every wave requests its pieces of W(t + 2), which lands in A(t)'s half-slot and has one unit to
+        // arrive, and of A(t + 3), which lands in W(t)'s and has two.  The wave groups stay staggered by half a unit, by program order:
+        // waves 0-3 run a unit between two barriers, waves 4-7 the second half of one unit and the first half of the next.
         const bool grpB = __builtin_amdgcn_readfirstlane(tid) >= (NWAVE / 2) * 64;
         constexpr int MH = MT / 2;
-        intx8 wf[4], af[MH];
+        constexpr int HALF_SLOT = 32768, NHS = 5;
+        static_assert(BN == 256 && PER_WAVE * NWAVE == (BM + BN) / 8, "one staging instruction per 8 rows");
+        constexpr int PW_A = BM / 8 / NWAVE, PW_W = BN / 8 / NWAVE;        // pieces per wave and unit: activation rows, weight rows
         constexpr bool DMA_ONLY = DBG == 2 || (DBG >= 12 && DBG <= 15);
+        intx8 wf[4], af[MH];
         if (DBG == 9 || DMA_ONLY) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wf[i] = intx8{lane, i, lane, 1, 2, lane, 3, 4};
@@ -449,12 +460,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             for (int i = 0; i < MH; ++i) af[i] = intx8{i, lane, 5, lane, 6, 7, lane, 8};
         }
         int sw[4], sa[MT];
-        // DMA sources without per-instruction vector registers: staging instruction i of this workgroup covers 8 rows x 128 bytes, row
-        // block i of the tile; a lane's source is  base + (first row of the block) * pitch + unit * 128  -- all scalar -- plus
-        // (lane / 8) * pitch + (chunk the lane's LDS position holds) * 16, and the chunk permutation ^ ((row >> 1) & 7) depends on the
-        // block only through its parity: two vector registers per operand instead of the general kernel's 32 (64-bit pointers), which
-        // this loop needs for the scale words.  Rows come in whole blocks (the launcher checks M % 8 == 0, N % 8 == 0 and that both
-        // images are below 4 GiB), so the clamp of the last tile is scalar too.
+        // DMA sources without per-instruction vector registers: a staging instruction covers 8 rows x 128 bytes; a lane's source is
+        // base + (first row of the block) * pitch + unit * 128  -- all scalar -- plus  (lane / 8) * pitch + (chunk its LDS position
+        // holds) * 16, and the chunk permutation ^ ((row >> 1) & 7) depends on the block only through its parity: two vector registers
+        // per operand instead of the general kernel's 64-bit pointers.  Rows come in whole blocks (the launcher checks M % 8 == 0,
+        // N % 8 == 0 and that both images are below 4 GiB), so the clamp of the last tile is scalar too.
         unsigned va[2], vw[2];
         {
             const int r = lane >> 3, pos8 = lane & 7;
@@ -465,25 +475,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             }
         }
         const int k0_bytes = k0_units * 128;
-        auto dma_piece = [&](int j, int tn, unsigned char* dst) {
-            const int i = wave * PER_WAVE + j;                              // wave-uniform
-            const bool isW = i >= NPA * A_INSTR;
-            const int blk = isW ? i - NPA * A_INSTR : i;
+        // piece j of this wave for unit u: j < PW_W weight rows, else activation rows
+        auto dma_piece = [&](int j, int u) {
+            const bool isW = j < PW_W;
+            const int blk = isW ? wave * PW_W + j : wave * PW_A + (j - PW_W);
             int row = (isW ? bn : bm) + blk * 8;
             const int lim = (isW ? g.N : g.M) - 8;
             row = row < lim ? row : lim;
-            const char* base = (const char*)(isW ? Whi : Ahi) + (int64_t)row * (isW ? g.ldw_mx : g.lda) * 2 + k0_bytes + (int64_t)tn * 128;   // a unit is 128 bytes of a row
+            const char* base = (const char*)(isW ? Whi : Ahi) + (int64_t)row * (isW ? g.ldw_mx : g.lda) * 2 + k0_bytes + (int64_t)u * 128;   // a unit is 128 bytes of a row
             unsigned o = isW ? vw[blk & 1] : va[blk & 1];
             asm volatile("" : "+s"(base), "+v"(o));  // keep the address a scalar base + a 32-bit vector offset (left alone, the zero-extended offsets are hoisted as 64-bit pairs)
-            // probe builds: DBG 12 .. 15 = the DMA-only form with a cache policy on the load (sc0, nt, sc1, sc0 sc1)
+            const int hs = (2 * u + (isW ? 1 : 0)) % NHS;
             constexpr int AUX = DBG == 12 ? 1 : DBG == 13 ? 2 : DBG == 14 ? 16 : DBG == 15 ? 17 : 0;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + o), (LDS_AS void*)(dst + dst_off[j]), 16, 0, AUX);
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(base + o), (LDS_AS void*)(smem + hs * HALF_SLOT + blk * 1024), 16, 0, AUX);
+        };
+        // the batch every wave requests behind barrier k: its pieces of W(k + 2), then of A(k + 3); pieces [j0, j1) of PER_WAVE
+        auto dma_batch = [&](int k, int j0, int j1) {
+            if (DBG == 1 && k > 0) return;
+#pragma unroll
+            for (int j = j0; j < j1; ++j) {
+                if (j < PW_W) { if (k + 2 < nk) dma_piece(j, k + 2); }
+                else if (k + 3 < nk) dma_piece(j, k + 3);
+            }
         };
         const unsigned char* a_s = (const unsigned char*)g.a_mxs;
         const unsigned char* w_s = (const unsigned char*)g.w_mxs;
-        auto load_scales = [&](int grp) {                       // grp: index of the 8-unit group within the whole K range
+        auto load_scales_into = [&](int grp, int* sw, int* sa) {    // grp: index of the 8-unit group within the whole K range
             // addresses are rebuilt from the lane's row index at every call (12 loads per 8 units): kept across the loop they are 24
-            // registers this kernel does not have (the compiler spilled them and reloaded each behind a vmcnt(0))
+            // registers this kernel does not have
             int frx = fr;
             asm volatile("" : "+v"(frx));
             const unsigned wstep = 4u * (unsigned)g.ldw_s, astep = 4u * (unsigned)g.lda_s;
@@ -500,8 +519,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 sa[i] = *(const int*)(a_s + ((unsigned)r * astep + (unsigned)(fq ^ 2) * (unsigned)g.lda_s + 4u * (unsigned)grp));
             }
         };
-        // the compiler's own wait for the scale loads lands HERE, next to a vmcnt(0) this wave executes anyway (it cannot see the
-        // counted waits of this loop: left to itself it would wait at the first fp8 instruction, in front of group B's P0)
+        auto load_scales = [&](int grp) { load_scales_into(grp, sw, sa); };
+        // the compiler's own wait for the scale loads lands HERE, next to a counted wait this wave executes anyway (it cannot see the
+        // counted waits of this loop: left to itself it would wait for vmcnt(0) at the first fp8 instruction)
         auto touch_scales = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(sw[i]));
@@ -515,18 +535,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             const intx4 a = __builtin_bit_cast(intx4, lo), b = __builtin_bit_cast(intx4, hi);
             return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-        auto read_w = [&](const unsigned char* cur) {
+        // fragment addresses: (row of the lane) * 128 + chunk * 16 inside a half-slot; chunk fq and chunk 4 + fq, permuted by ^ ((row >> 1) & 7)
+        const int sx = (fr >> 1) & 7;
+        const int fa0 = (wm * WROWS + fr) * 128 + ((fq ^ sx) * 16), fa1 = (wm * WROWS + fr) * 128 + (((4 + fq) ^ sx) * 16);
+        const int fw0 = (wn * 64 + fr) * 128 + ((fq ^ sx) * 16), fw1 = (wn * 64 + fr) * 128 + (((4 + fq) ^ sx) * 16);
+        auto read_w = [&](int u) {
+            const unsigned char* b = smem + ((2 * u + 1) % NHS) * HALF_SLOT;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = cat(w_frag(cur, i, 0, 0), w_frag(cur, i, 1, 0));
+            for (int i = 0; i < 4; ++i) wf[i] = cat(*(const half8*)(b + fw0 + i * 2048), *(const half8*)(b + fw1 + i * 2048));
         };
-        auto read_a = [&](const unsigned char* cur, int mh) {
+        auto read_a = [&](int u, int mh) {
+            const unsigned char* b = smem + ((2 * u) % NHS) * HALF_SLOT;
 #pragma unroll
-            for (int i = 0; i < MH; ++i) af[i] = cat(a_frag(cur, mh * MH + i, 1, 0), a_frag(cur, mh * MH + i, 0, 0));
+            for (int i = 0; i < MH; ++i) af[i] = cat(*(const half8*)(b + fa1 + (mh * MH + i) * 2048), *(const half8*)(b + fa0 + (mh * MH + i) * 2048));
         };
-        auto mfma_half = [&](auto kind_c, int mh, int tn, int sn) {   // kind 0: f16 unit; 1 .. 4: fp8 unit, scale byte kind - 1
+        // MH m-tiles of MFMAs of unit kind KIND (0: f16 unit; 1 .. 4: fp8 unit, scale byte KIND - 1); the pieces of batch k (k < -1: none)
+        // go out between the m-tiles
+        auto mfma_half = [&](auto kind_c, int mh, int k, bool dma) {
             constexpr int KIND = decltype(kind_c)::value;
-            const bool dma = tn >= 0 && tn < nk && DBG != 1;
-            unsigned char* nxt = smem + sn * STAGE;
 #pragma unroll
             for (int mt = 0; mt < MH; ++mt) {
 #pragma unroll
@@ -542,53 +568,74 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     }
                     acc[mh * MH + mt][nt] = c;
                 }
-                if (dma) {
-#pragma unroll
-                    for (int j = (mt * PER_WAVE) / MH; j < ((mt + 1) * PER_WAVE) / MH; ++j) dma_piece(j, tn, nxt);
-                }
+                if (dma) dma_batch(k, (mt * PER_WAVE) / MH, ((mt + 1) * PER_WAVE) / MH);
             }
         };
-        auto unit = [&](auto kind_c, auto first_c, int t) {
-            constexpr bool FIRST = decltype(first_c)::value;             // first unit of a group: the scale loads were just issued
-            const unsigned char* cur = smem + (t & 1) * STAGE;
-            // probe builds: DBG 1 no DMA in the steady state, 2 DMA only, 9 no fragment reads (stale registers), 10 / 11 only the f16 / fp8 units multiply
-            if (!DMA_ONLY && DBG != 9) { read_w(cur); read_a(cur, 0); }
-            mfma_half(kind_c, 0, grpB ? -1 : t + 1, (t + 1) & 1);
-            if (!DMA_ONLY && DBG != 9) read_a(cur, 1);
-            if (grpB) { wait_vmcnt<0>(); if (FIRST) touch_scales(); }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            mfma_half(kind_c, 1, grpB ? t + 2 : -1, t & 1);
-            if (!grpB) { wait_vmcnt<0>(); if (FIRST) touch_scales(); }
-            __builtin_amdgcn_s_barrier();
+        auto kind_of = [](auto r_c) { constexpr int R = decltype(r_c)::value; return std::integral_constant<int, (R & 1) ? 1 + (R >> 1) : 0>{}; };
+        auto frag_p0 = [&](int t) { if (!DMA_ONLY && DBG != 9) { read_w(t); read_a(t, 0); } };
+        auto frag_p1 = [&](int t) { if (!DMA_ONLY && DBG != 9) read_a(t, 1); };
+        // everything but the youngest batch's activation pieces (and, where said, the scale loads behind them) has landed
+        auto wait_landed = [&](int t, bool scales_behind) {
+            if (t + 2 < nk && !(DBG == 1 && t > 1)) { if (scales_behind) wait_vmcnt<PW_A + 4 + MT>(); else wait_vmcnt<PW_A>(); }
+            else wait_vmcnt<0>();
         };
-        typedef std::integral_constant<int, 0> k0_t;
-        typedef std::integral_constant<bool, true> yes_t;
-        typedef std::integral_constant<bool, false> no_t;
+        // ---- prologue: A(0), W(0), A(1) (the batches "-3" and "-2" of the steady state); unit 0 landed behind the barrier
 #pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) dma_piece(j, 0, smem);
-        if (grpB && nk > 1) {
+        for (int j = PW_W; j < PER_WAVE; ++j) dma_piece(j, 0);
 #pragma unroll
-            for (int j = 0; j < PER_WAVE; ++j) dma_piece(j, 1, smem + STAGE);
-            wait_vmcnt<PER_WAVE>();
+        for (int j = 0; j < PW_W; ++j) dma_piece(j, 0);
+        if (nk > 1) {
+#pragma unroll
+            for (int j = PW_W; j < PER_WAVE; ++j) dma_piece(j, 1);
+            wait_vmcnt<PW_A>();
         } else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (grpB) __builtin_amdgcn_s_barrier();                  // B starts one phase late
-        for (int tg = 0; tg < nk; tg += 8) {                     // nk is even (K % 64 == 0; parts are whole groups)
-            load_scales((k0_units + tg) >> 3);
-            unit(k0_t{}, yes_t{}, tg);
-            unit(std::integral_constant<int, 1>{}, no_t{}, tg + 1);
+        __builtin_amdgcn_s_barrier();                                  // barrier "-1"
+        // One loop body for both groups (two loops, one per group, met at the epilogue with the accumulators in different registers:
+        // 70 spilled).  Waves 0-3: between barrier t - 1 and barrier t the whole unit t, batch t - 1 under its first half.  Waves 4-7,
+        // half a unit behind: their barrier t sits in the MIDDLE of unit t -- between two barriers they run the second half of unit
+        // t - 1, with batch t - 1 under it, and the first half of unit t (whose first unit carries batch -1).  Scale words of a group:
+        // waves 0-3 request them at the top of its first unit, waves 4-7 at the top of the previous group's last second half (into
+        // registers of their own: that half still multiplies with the old ones) -- both IN FRONT of a batch, so that the counted
+        // wait before the next barrier covers them.
+        auto unit = [&](auto r_c, int t) {
+            constexpr int R = decltype(r_c)::value;
+            // scale words of this group: requested at the top of its first unit.  Waves 0-3: in front of batch t - 1 -- the counted wait
+            // before barrier t covers them.  Waves 4-7: BEHIND batch t - 1 (it went out under the previous second half; the first group
+            // aside) -- they stay in flight across barrier t and are waited for in front of the group's first fp8 instructions, behind
+            // batch t (no register of their own for a prefetch: 16 accumulators were spilled for it)
+            if (R == 0) load_scales((k0_units + t) >> 3);
+            if (R == 1 && grpB) {
+                if (t + 2 < nk) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
+                touch_scales();
+            }
+            frag_p0(t);
+            mfma_half(kind_of(r_c), 0, t - 1, !grpB || t == 0);
+            frag_p1(t);
+            if (grpB) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every fragment of unit t is in registers: its half-slots may go
+                if (R == 0 && t != 0) wait_landed(t, true); else wait_landed(t, false);
+                __builtin_amdgcn_s_barrier();                          // barrier t
+            }
+            mfma_half(kind_of(r_c), 1, t, grpB);
+            if (!grpB) {
+                wait_landed(t, false);
+                if (R == 0) touch_scales();
+                __builtin_amdgcn_s_barrier();                          // barrier t
+            }
+        };
+        for (int tg = 0; tg < nk; tg += 8) {                         // nk is even (K % 64 == 0; parts are whole groups)
+            unit(std::integral_constant<int, 0>{}, tg);
+            unit(std::integral_constant<int, 1>{}, tg + 1);
             if (tg + 2 >= nk) break;
-            unit(k0_t{}, no_t{}, tg + 2);
-            unit(std::integral_constant<int, 2>{}, no_t{}, tg + 3);
+            unit(std::integral_constant<int, 2>{}, tg + 2);
+            unit(std::integral_constant<int, 3>{}, tg + 3);
             if (tg + 4 >= nk) break;
-            unit(k0_t{}, no_t{}, tg + 4);
-            unit(std::integral_constant<int, 3>{}, no_t{}, tg + 5);
+            unit(std::integral_constant<int, 4>{}, tg + 4);
+            unit(std::integral_constant<int, 5>{}, tg + 5);
             if (tg + 6 >= nk) break;
-            unit(k0_t{}, no_t{}, tg + 6);
-            unit(std::integral_constant<int, 4>{}, no_t{}, tg + 7);
+            unit(std::integral_constant<int, 6>{}, tg + 6);
+            unit(std::integral_constant<int, 7>{}, tg + 7);
         }
-        if (!grpB) __builtin_amdgcn_s_barrier();                  // match B's extra leading barrier
     } else if (NSTAGE == 5) {
         // Two slots, wave groups staggered by half a K-tile (MT = 8, BK = 32).  Waves 0..3 (group A) and 4..7
         // (group B) share SIMDs pairwise (wave w and w+4).  Each K-tile has two phases per wave,
@@ -722,7 +769,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         int lane_x = lane;
         asm volatile("" : "+v"(lane_x));
         if (kpart > 0) {
-            __shared__ int tail_gave_up;
+            // (the mx kernel's ring is the whole dynamic LDS of a workgroup: its flag is the last word of the ring, which the loop has left)
+            int* gave_up_p;
+            if constexpr (MX) gave_up_p = (int*)(smem + 5 * 32768 - 16);
+            else { __shared__ int tail_gave_up_word; gave_up_p = &tail_gave_up_word; }
+            int& tail_gave_up = *gave_up_p;
             if (tid == 0) {
                 int spins = 0, bad = 0;
                 while (__hip_atomic_load(&p.flags[tail_j * 4 + kpart - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {

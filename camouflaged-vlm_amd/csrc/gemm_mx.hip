@@ -6,7 +6,7 @@ using namespace cvlm_gemm_k;
 
 template <int MT_, int EPI_, int DBG_>
 static int launch_one(GemmParams& p, int extra_blocks, hipStream_t s) {
-    constexpr int smem_ = 2 * 2 * (MT_ * 32 + 256) * 32 * 2;
+    constexpr int smem_ = 5 * 32768;                                      // the ring: five half-slots (gemm_kernel.h, MX branch)
     p.nbx = (p.a.N + 255) / 256;
     p.nby = (p.a.M + MT_ * 32 - 1) / (MT_ * 32);
     auto kern_ = gemm_nt_kernel<3, 2, 4, 5, 32, DBG_, MT_, false, EPI_, false, false, true, true, true>;

@@ -97,6 +97,7 @@ class CustomCLIP(nn.Module):
     def _drop_engine_hook(module, incompatible_keys) -> None:
         module._engine = None
         module._engine_text_dirty = True
+        module._engine_train_dirty = True
 
     # ---- weights -------------------------------------------------------------------------------
     def _load_from_clip(self, clip_model, tokens_train=None, tokens_test=None) -> None:
@@ -148,12 +149,14 @@ class CustomCLIP(nn.Module):
                 loaded.update({"prompt_learner.token_prefix" + sfx, "prompt_learner.token_suffix" + sfx})
         self._engine = None
         self._engine_text_dirty = True
+        self._engine_train_dirty = True
         self.loaded_from_clip = sorted(loaded)
 
     def load_text_features(self, train_text_features, test_text_features):
         self.train_text_features = train_text_features
         self.test_text_features = test_text_features
         self._engine_text_dirty = True
+        self._engine_train_dirty = True
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -182,6 +185,7 @@ class CustomCLIP(nn.Module):
             sd = {k: v for k, v in self.state_dict().items()}
             self._engine = ClipModel(sd, self.geometry, dev, prec, prefix="")
             self._engine_text_dirty = True
+            self._engine_train_dirty = True
         if getattr(self, "_engine_text_dirty", True):
             bank = self.test_text_features
             if bank is None:
@@ -193,9 +197,19 @@ class CustomCLIP(nn.Module):
         return self._engine
 
     def forward(self, image, mask, label=None, train=False):
-        if train:
-            raise NotImplementedError("training branch (mapleAlphaCLIP.py:267-280) is outside the inference path")
-        return self.engine().forward(image.float().contiguous(), mask.float().contiguous(), "test")
+        """cocotrainers/mapleAlphaCLIP.py:264-294.  train=True (:267-280) is the same forward-only arithmetic on the TRAIN prompts
+        (`prompt_learner()` instead of `forward_test()`) and the train bank -> logits [B][n_cls_train]; nothing on this path takes
+        gradients (the training loop itself, losses and optimizer, is out of scope)."""
+        eng = self.engine()
+        if not train:
+            return eng.forward(image.float().contiguous(), mask.float().contiguous(), "test")
+        if getattr(self, "_engine_train_dirty", True) or "train" not in eng.txt:
+            if self.train_text_features is None:
+                raise RuntimeError("text features not loaded: call load_text_features(train, test) first "
+                                   "(models/sam_maskdecoder_edge.py:190)")
+            eng.set_text_bank(gather_text_features(eng, self._eot("train"), "train"), self.train_text_features, "train")
+            self._engine_train_dirty = False
+        return eng.forward(image.float().contiguous(), mask.float().contiguous(), "train")
 
 
 class TestMaPLeAlphaCLIP(nn.Module):

@@ -113,23 +113,26 @@ class Linear:
     normal range, K zero-padded to a multiple of 32, optional N padding (zero rows)."""
 
     def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], device, n_pad: int = 0, k_pad: int = 0, il: bool = True, mx: bool = False):
-        w = w.detach().float().reshape(w.shape[0], -1).cpu()
+        # Packed ON THE DEVICE (round 5): the planes, the 128-byte-row image and the mx image of 1.04 G parameters were 25-60 s of host
+        # time per process -- times the ranks of a node that share its CPU quota; the host only reshapes.  Same arithmetic (fp16 / e4m3
+        # round-to-nearest conversions of torch on either device; tests/test_gemm_mx_gpu.py holds the device's mx_pack to the host's).
+        w = w.detach().float().reshape(w.shape[0], -1)
         N, K = w.shape
         self.N = max(N, n_pad)
         self.K = max(_ceil(K, 32), k_pad)
-        wp = torch.zeros(self.N, self.K)
-        wp[:N, :K] = w
-        mx = float(wp.abs().max())
-        e = 0 if mx == 0.0 else int(math.floor(math.log2(2048.0 / mx)))
+        wp = torch.zeros(self.N, self.K, device=device)
+        wp[:N, :K] = w.to(device)
+        mx_abs = float(wp.abs().max())
+        e = 0 if mx_abs == 0.0 else int(math.floor(math.log2(2048.0 / mx_abs)))
         e = max(min(e, 24), -24)
         self.alpha = float(2.0 ** (-e))
         planes = H2.pack(wp * (2.0 ** e))
-        self.w = H2(planes.t.to(device))
+        del wp
+        self.w = planes
         # third image: the mx operand (cvlm_gemm_args.w_mx, ABI 10) for the launches whose activation is an mx image
         self.w_mx = None
         if mx and self.K % 64 == 0 and self.N * self.K >= (1 << 18):
-            m = hip.H2MX.from_planes(planes)
-            self.w_mx = hip.H2MX(m.t.to(device), m.s.to(device), None, m.C)
+            self.w_mx = hip.H2MX.from_planes(planes)
         # second image with the planes interleaved per 32 k-elements (cvlm_gemm_args.w_il, ABI 6): what the big-tile kernels stage
         # the weight from; small matrices never reach those kernels, and `il=False` marks weights that only the tap / fallback
         # schedules launch (the unfused twins of LayerNorm-folded GEMMs): they stay planar and cost no second copy
@@ -287,11 +290,15 @@ class SamEncoder(_Base):
         ws, sp, KN = self.ws, self.prec.gemm, self.hp_k
         # KN > N (N not a multiple of 32): the image / P^T / Q^T rows keep their pitch N and the K-tiles of a row run up to 31 elements
         # into the next row -- finite numbers that meet the zero columns of L.  The last row of a plane runs into the next plane or
-        # into `slack` zero elements behind the buffer (zero-filled when allocated, never written).
+        # into `slack` elements behind it.  Those are zeroed on EVERY call: the workspace hands out the head of the largest
+        # buffer seen so far, so after a larger batch the slack of a smaller one lies inside stale data, and 0 * inf is not 0.
         slack = KN - N
-        xs = ws.h2("hp_x", B * C * N * N + slack, zero=slack > 0)   # flat planes: [B*C*N rows][N] + slack
+        xs = ws.h2("hp_x", B * C * N * N + slack)                   # flat planes: [B*C*N rows][N] + slack
         hip.split_f32(inp, xs)                                      # writes numel(inp) elements at the head of each plane
-        pq = ws.h2("hp_pq", B * C * 2 * N * N + slack, zero=slack > 0)       # per problem: rows [0,N) = P^T, [N,2N) = Q^T
+        pq = ws.h2("hp_pq", B * C * 2 * N * N + slack)              # per problem: rows [0,N) = P^T, [N,2N) = Q^T
+        if slack > 0:
+            xs.t[:, B * C * N * N:].zero_()
+            pq.t[:, B * C * 2 * N * N:].zero_()
         hip.gemm(self.lstack, xs, 2 * N, N, KN, lda=KN, ldw=N, out_h2=pq, ldoh=N, batch=B * C, stride_a=0, stride_w=N * N,
                  stride_oh=2 * N * N, split=sp)
         t = ws.f32("hp_t", B, C, N, N)
@@ -908,7 +915,7 @@ class ClipModel(_Base):
             return dict(inp=Linear(ipw, ipb, device),
                         out=Linear(sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], device),
                         fc=Linear(sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"], device),
-                        pj=Linear(sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], device),
+                        pj=Linear(sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"], device, mx=precision.mx and not text),
                         ln1=(self.dev(sd[p + "ln_1.weight"]), self.dev(sd[p + "ln_1.bias"])),
                         ln2=(self.dev(sd[p + "ln_2.weight"]), self.dev(sd[p + "ln_2.bias"])))
 
@@ -979,6 +986,11 @@ class ClipModel(_Base):
         hid_il = (os.environ.get("CVLM_GEMM_AIL", "1") not in ("0", "b") or M > 4096) and os.environ.get("CVLM_GEMM_AIL", "1") != "0" \
             and pr.gemm == 3 and (4 * Wd) % 32 == 0 and all(b["pj"].w_il is not None and b["fc_f"].w_il is not None for b in self.vblocks)
         hid = ws.h2il("vhid_il", M, 4 * Wd) if hid_il else ws.h2("vhid", M, 4 * Wd)
+        # precision `mx`: the hidden rows as an mx operand (SamEncoder._blocks_folded): c_proj, a third of the tower's GEMM flops, runs
+        # its two correction products on the block-scaled e4m3 instruction.  (in_proj / c_fc read the residual stream, whose planes the
+        # deep prompts overwrite row by row: it stays in planes.)
+        if hid_il and pr.mx and (4 * Wd) % 64 == 0 and M % 8 == 0 and all(b["pj"].w_mx is not None for b in self.vblocks):
+            hid = ws.h2mx("vhid_mx", M, 4 * Wd)
         pcs, mrg = ws.f32("vln_pieces", hip.stats_pieces(Wd), M, 2), ws.f32("vln_merged", M, 2)
         gws = self.ws.gemm_ws()
         hip.row_stats_split(x.view(M, Wd), X_SCALE, xh, pcs, M, Wd)
@@ -1137,7 +1149,7 @@ class Cascade(_Base):
         self._side = None
         self._done = [None, None]                                    # side-stream completion events of the last two batches
         self._parity = 0
-        self._guard, self._guard_host, self._refused_seen, self.fold_refusals = None, None, 0, 0
+        self._guard, self._guard_host, self._guard_free, self._refused_seen, self.fold_refusals = [], None, [], 0, 0
 
     # ---- LayerNorm-fold refusal guard ---------------------------------------------------------------------------
     # A row with |mu| / sigma > 128 cannot be served by the folded LayerNorm within the error budget:
@@ -1147,21 +1159,31 @@ class Cascade(_Base):
     # next call that finds the copy complete and a counter raised switches BOTH towers to the separate two-pass LayerNorm
     # schedule for the rest of the model's life and says so.  The batch that met the rows has NaN outputs (loud); every later
     # batch is served.
+    # The refusal guard: after every forward the two refusal counters (word 513 of the encoder's and the CLIP
+    # tower's GEMM workspaces; cumulative) are copied to pinned host memory asynchronously; a later call that finds a copy complete and a
+    # counter raised switches both towers to the separate LayerNorm passes.  The copies in flight form a FIFO over a small pool of pinned
+    # slots and the check polls the OLDEST (one slot re-armed on every call is never complete when the next call looks at it
+    # in a loop that runs ahead of the GPU -- the pipelined loops -- and the switch never fired there).  With every slot in flight a
+    # call arms nothing: the counters are cumulative, a later copy carries the same news.
+    _GUARD_SLOTS = 4
+
     def _fold_guard_check(self) -> None:
-        g = self._guard
-        if g is None or torch.cuda.is_current_stream_capturing() or not g[1].query():
-            return                                                   # (an event query would invalidate a hipGraph capture)
-        self._guard = None
-        refused = int(g[0][0]) + int(g[0][1])
-        if refused > self._refused_seen:
-            self._refused_seen = refused
-            self.fold_refusals = refused
-            self.encoder.fold_disabled = True
-            self.clip.fold_disabled = True
-            import warnings
-            warnings.warn(f"camouflaged_vlm_amd: {refused} token row(s) with |mean| / std > 128 were refused by the folded LayerNorm "
-                          "(their images came out NaN); switching to the separate LayerNorm passes from this batch on "
-                          "(set CVLM_LN_FOLD=0 to start that way)", RuntimeWarning, stacklevel=3)
+        if torch.cuda.is_current_stream_capturing():                 # (an event query would invalidate a hipGraph capture)
+            return
+        q = self._guard
+        while q and q[0][1].query():
+            slot, _ = q.pop(0)
+            refused = int(self._guard_host[slot, 0]) + int(self._guard_host[slot, 1])
+            self._guard_free.append(slot)
+            if refused > self._refused_seen:
+                self._refused_seen = refused
+                self.fold_refusals = refused
+                self.encoder.fold_disabled = True
+                self.clip.fold_disabled = True
+                import warnings
+                warnings.warn(f"camouflaged_vlm_amd: {refused} token row(s) with |mean| / std > 128 were refused by the folded LayerNorm "
+                              "(their images came out NaN); switching to the separate LayerNorm passes from this batch on "
+                              "(set CVLM_LN_FOLD=0 to start that way)", RuntimeWarning, stacklevel=3)
 
     def _fold_guard_arm(self, stream) -> None:
         if not ((self.encoder.ln_fold and not self.encoder.fold_disabled) or (self.clip.ln_fold and not self.clip.fold_disabled)):
@@ -1169,15 +1191,21 @@ class Cascade(_Base):
         if torch.cuda.is_current_stream_capturing():                 # a captured step carries no host-side check: the caller of a
             return                                                   # graph reads ws.gemm_errors() itself (tools/graph_step.py)
         if self._guard_host is None:
-            self._guard_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._guard_host = torch.zeros(self._GUARD_SLOTS, 2, dtype=torch.int32).pin_memory()
+            self._guard_free = list(range(self._GUARD_SLOTS))
+        if not self._guard_free:
+            return
+        slot = self._guard_free.pop(0)
         with torch.cuda.stream(stream):
             for k, eng in enumerate((self.encoder, self.clip)):
                 w = eng.ws._gemm_ws
                 if w is not None:
-                    self._guard_host[k:k + 1].copy_(w[2052:2056].view(torch.int32), non_blocking=True)   # word 513
+                    self._guard_host[slot, k:k + 1].copy_(w[2052:2056].view(torch.int32), non_blocking=True)   # word 513
+                else:
+                    self._guard_host[slot, k] = 0
             ev = torch.cuda.Event()
             ev.record(stream)
-        self._guard = (self._guard_host, ev)
+        self._guard.append((slot, ev))
 
     def sparse_prompts(self, img_f: torch.Tensor, txt_f: torch.Tensor, B: int) -> torch.Tensor:
         """models/sam_maskdecoder_edge.py:342-344."""
@@ -1391,6 +1419,25 @@ class Cascade(_Base):
         for t in (masks, pred, logits):
             t.record_stream(main)
         return masks, pred, logits
+
+    def batch_done_event(self) -> "torch.cuda.Event":
+        """Event behind everything the LAST `cascade(pipelined=True)` call put on the side stream: that batch's decoder and, in front of
+        it, the forward that filled the PREVIOUS batch's pred / logits.  A consumer on another stream (DeviceEvalLoop's tail stream)
+        waits for it instead of reading the engine's bookkeeping.  Valid for every configuration: where a call left no
+        side-stream event (no side stream in use), one is recorded on the current stream."""
+        ev = self._done[self._parity ^ 1]
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        return ev
+
+    def results_ready_event(self) -> "torch.cuda.Event":
+        """After `flush()`: event behind the forward that filled the last owed pred / logits."""
+        ev = self._clip_done if self._clip_done is not None else self._done[self._parity ^ 1]
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+        return ev
 
     def flush(self) -> None:
         """Launch the stage 2 that `cascade(pipelined=True)` still owes for its last batch (no-op otherwise); results are

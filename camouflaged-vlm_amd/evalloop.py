@@ -114,7 +114,7 @@ class DeviceEvalLoop:
         if self._tail_stream is None:
             self._tail_stream = torch.cuda.Stream(device=self.device)
         masks, pred, logits = cas.cascade(inp, clip_image, clip_mask, pipelined=True)
-        done = cas._done[cas._parity ^ 1]                             # side stream: this batch's decoder is through -- and, in front of it,
+        done = cas.batch_done_event()                                 # side stream: this batch's decoder is through -- and, in front of it,
         self._mark(marks)                                             # the fused CLIP forward that filled the PREVIOUS batch's pred / logits
         if self._owed is not None:
             self._run_tail(self._owed, done)
@@ -135,7 +135,7 @@ class DeviceEvalLoop:
         if self.pipelined and self._owed is not None:
             cas = self.model.cascade()
             cas.flush()                                               # the last batch's stage 2 (no-op when nothing is owed there)
-            self._run_tail(self._owed, cas._clip_done if cas._clip_done is not None else cas._done[cas._parity ^ 1])
+            self._run_tail(self._owed, cas.results_ready_event())
             self._owed = None
         torch.cuda.synchronize(self.device)
         return self.metricer.show(num_bits=None), dict(self.evaluator.evaluate())

@@ -13,6 +13,7 @@ several units, logit_scale = ln(100).
 from __future__ import annotations
 
 import hashlib
+import os
 import math
 from typing import Dict, Iterable, Tuple
 
@@ -71,13 +72,37 @@ def make_tensor(name: str, shape: Tuple[int, ...], kind: str, seed: int = 0) -> 
     raise ValueError(f"unknown tensor kind {kind!r} for {name}")
 
 
-def make_state_dict(entries: Iterable[Entry], seed: int = 0) -> Dict[str, np.ndarray]:
-    return {name: np.ascontiguousarray(make_tensor(name, shape, kind, seed), dtype=np.float32)
-            for name, shape, kind in entries}
+def make_state_dict(entries: Iterable[Entry], seed: int = 0, threads: int = 0) -> Dict[str, np.ndarray]:
+    """Every tensor has its own counter-based generator (keyed by its name), so the tensors can be drawn in any order and in
+    parallel: `threads` worker threads (0: min(8, CPUs the process may use); numpy's generators release the GIL).  1.04 G parameters of
+    the demo geometry take ~30 s on one thread -- times eight when eight ranks of one node build the same model."""
+    entries = list(entries)
+    if threads <= 0:
+        try:
+            threads = min(8, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            threads = min(8, os.cpu_count() or 1)
+    one = lambda e: np.ascontiguousarray(make_tensor(e[0], e[1], e[2], seed), dtype=np.float32)
+    if threads == 1 or len(entries) < 8:
+        return {e[0]: one(e) for e in entries}
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        vals = list(ex.map(one, entries))
+    return {e[0]: v for e, v in zip(entries, vals)}
+
+
+_FULL_CACHE: Dict[tuple, Dict[str, np.ndarray]] = {}
 
 
 def make_full_state_dict(g: SamGeometry, c: ClipGeometry, seed: int = 0) -> Dict[str, np.ndarray]:
-    return make_state_dict(full_entries(g, c), seed)
+    """The assembled model's 1195 tensors.  The last two results are kept (a test session builds the demo geometry's 4 GB a dozen
+    times): callers get a fresh dict of the SAME arrays and must copy before they modify one (apply_outliers does)."""
+    key = (g, c, seed)
+    if key not in _FULL_CACHE:
+        while len(_FULL_CACHE) >= 2:
+            _FULL_CACHE.pop(next(iter(_FULL_CACHE)))
+        _FULL_CACHE[key] = make_state_dict(full_entries(g, c), seed)
+    return dict(_FULL_CACHE[key])
 
 
 def make_text_bank(n_cls: int, dim: int, split: str, seed: int = 0) -> np.ndarray:

@@ -236,7 +236,9 @@ int64_t cvlm_attention_workspace_bytes(const cvlm_attn_args* args);
 
 /* Small fp32 attention for the two-way decoder (transformer_maskdecoder_edge.py:250-272):
  * q f32 [B][nq][heads*hd] (ldq), k,v f32 [B][nk][heads*hd]; out f32 [B][nq][heads*hd].
- * softmax(q.k / sqrt(hd)) v per head; any nq/nk. */
+ * softmax(q.k / sqrt(hd)) v per head; any nq/nk.  Since ABI 7 this entry is cvlm_small_attention_h2 without the h2 output and shares
+ * its limits: hd = 16 or 32 (anything else: CVLM_E_UNSUPPORTED), row pitches multiples of 4 floats and bases 16-byte aligned
+ * (otherwise CVLM_E_BADARG) -- the scalar-load form that served other head dims and alignments is gone. */
 int cvlm_small_attention(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                          float* out, int64_t ldo, int32_t B, int32_t nq, int32_t nk, int32_t heads, int32_t hd,
                          void* stream);

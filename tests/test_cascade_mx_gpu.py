@@ -1,0 +1,156 @@
+"""Precision `mx` (include/cvlm.h ABI 10; engine.Precision.named("mx")) end to end at the full demo.yaml geometry: the ViT-H qkv / lin1 /
+lin2 GEMMs and the CLIP tower's c_proj with their two correction products on the block-scaled e4m3 matrix instruction, against the
+digests of the REFERENCE's own outputs (tests/golden/demo_digest.npz, hires1536_digest.npz; one B = 1 forward per image).
+
+Adoption gate of the mode: mask logits <= 5e-4, class logits <= 2.5e-4, IoU >= 0.9999, equal predictions on EVERY one of
+the 16 reference images -- twice inside the north-star gate (1e-3 / 0.999) that digest.check_* applies.
+The tiny test geometry (D = 160) has no mx launches (K % 64 != 0); the operator-level tests are tests/test_gemm_mx_gpu.py.
+"""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MX_MASK_TOL, MX_LOGIT_TOL, MX_IOU = 5e-4, 2.5e-4, 0.9999
+BATCH_TOL = 2e-4            # a batch against its single-image forwards in this mode (K-parts and tile forms differ with M)
+
+
+@pytest.fixture(scope="module")
+def demo_mx(golden_dir):
+    from camouflaged_vlm_amd import spec, synth
+    from camouflaged_vlm_amd.engine import Cascade, Precision
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    with np.load(os.path.join(golden_dir, "demo_digest.npz")) as z:
+        dg = {k: z[k] for k in z.files}
+    with np.load(os.path.join(golden_dir, "ovcamo_constants.npz")) as z:
+        bank = torch.from_numpy(z["bank_test"]).float()
+    g, c = spec.DEMO_SAM, spec.DEMO_CLIP
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_full_state_dict(g, c).items()}
+    cas = Cascade(sd, g, c, dev, Precision.named("mx"))
+    del sd
+    cas.clip.set_text_bank(cas.clip.text_features(dg["eot_test"].tolist(), "test"), bank, "test")
+    return cas, dg, g, c, dev
+
+
+def gate(r):
+    assert r["ok"], r
+    assert r["max_abs_mask_err"] <= MX_MASK_TOL and r["max_abs_class_logit_err"] <= MX_LOGIT_TOL and r["min_iou"] >= MX_IOU and r["pred_equal"], r
+
+
+def test_mx_mode_runs_the_mx_kernels(demo_mx):
+    """The mode is what it says: the encoder's weights carry mx images and a forward launches cvlm_gemm with mx operands."""
+    from camouflaged_vlm_amd import hip, synth
+    cas, dg, g, c, dev = demo_mx
+    blk = cas.encoder.blocks[1]
+    assert blk["qkv_f"].w_mx is not None and blk["lin1_f"].w_mx is not None and cas.encoder.lin2cat[0].w_mx is not None
+    assert cas.clip.vblocks[0]["pj"].w_mx is not None
+    seen = {"a_mx": 0, "out_mx": 0, "res_mx": 0}
+    orig = hip.gemm
+
+    def spy(a, w, M, N, K, **kw):
+        seen["a_mx"] += bool(getattr(a, "mx", False))
+        seen["out_mx"] += bool(getattr(kw.get("out_h2"), "mx", False))
+        seen["res_mx"] += bool(kw.get("residual_h2") is not None and getattr(kw["residual_h2"][0], "mx", False))
+        return orig(a, w, M, N, K, **kw)
+    hip.gemm = spy
+    try:
+        inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=1))
+        cas.cascade(inp, ci, cm)
+    finally:
+        hip.gemm = orig
+    # per ViT-H block: qkv (but block 0's), lin1, lin2 read mx operands; proj, lin1, the prompt GEMM and lin2 (but the last) write them
+    assert seen["a_mx"] >= 3 * g.depth - 1 and seen["out_mx"] >= 4 * g.depth - 2 and seen["res_mx"] >= 2 * g.depth - 1, seen
+
+
+def test_mx_demo_geometry_all_16_reference_images(demo_mx):
+    """Both batches bench.py times (B = 8), every image against the reference; a second run bit for bit; no hand-off errors."""
+    from camouflaged_vlm_amd import digest, synth
+    cas, dg, g, c, dev = demo_mx
+    worst = {"mask": 0.0, "logit": 0.0, "iou": 1.0}
+    for k in range(2):
+        ids = list(range(8 * k, 8 * k + 8))
+        per = [synth.make_inputs(g, c, batch=1, index0=i) for i in ids]
+        inp, ci, cm = (torch.from_numpy(np.concatenate([p[j] for p in per])).to(dev) for j in range(3))
+        m, p, l = cas.cascade(inp, ci, cm)
+        m, p, l = m.clone(), p.clone(), l.clone()
+        assert bool(torch.isfinite(m).all()) and bool(torch.isfinite(l).all())
+        r = digest.check_cascade(m, p, l, dg, ids)
+        assert r["checked_images"] == ids
+        gate(r)
+        worst = {"mask": max(worst["mask"], r["max_abs_mask_err"]), "logit": max(worst["logit"], r["max_abs_class_logit_err"]),
+                 "iou": min(worst["iou"], r["min_iou"])}
+        if k == 0:
+            again = cas.cascade(inp, ci, cm)
+            assert torch.equal(again[0], m) and torch.equal(again[2], l)          # bit-reproducible run to run
+            m1, p1, l1 = cas.cascade(inp[3:4], ci[3:4], cm[3:4])
+            assert float((m1 - m[3:4]).abs().max()) < BATCH_TOL and float((l1 - l[3:4]).abs().max()) < BATCH_TOL
+            assert p1.cpu().tolist() == p[3:4].cpu().tolist()
+    print(f"mx, demo geometry, 16 reference images: mask {worst['mask']:.2e} class logits {worst['logit']:.2e} IoU {worst['iou']:.6f}")
+    for eng in (cas, cas.encoder, cas.decoder, cas.clip):
+        assert eng.ws.gemm_errors() == 0
+
+
+def test_mx_pipelined_loop_with_changing_batches(demo_mx):
+    """The loop bench.py times (`cascade(pipelined=True)`, stage 2 fused with the next batch's CLIP pass 1) fed 8 / 3 / 8 other / 1 images."""
+    from camouflaged_vlm_amd import digest, synth
+    cas, dg, g, c, dev = demo_mx
+    plan = [list(range(0, 8)), [8, 9, 10], list(range(8, 16)), [5]]
+    outs = []
+    for ids in plan:
+        per = [synth.make_inputs(g, c, batch=1, index0=i) for i in ids]
+        inp, ci, cm = (torch.from_numpy(np.concatenate([p[j] for p in per])).to(dev) for j in range(3))
+        outs.append(cas.cascade(inp, ci, cm, pipelined=True))
+    cas.flush()
+    torch.cuda.synchronize()
+    for ids, (m, p, l) in zip(plan, outs):
+        r = digest.check_cascade(m, p, l, dg, ids)
+        assert r["checked_images"] == ids
+        gate(r)
+
+
+def test_mx_outlier_weights_stay_with_the_split3_engine(golden_dir):
+    """Massive residual channels (x1e3, x1e4), a dead channel, hot MLP units (synth.apply_outliers) at the demo geometry: the block
+    exponents of the mx operands follow them.  No reference digest exists for these weights at full size (the reference run on them
+    is pinned at the tiny geometry, test_outlier_channels_match_reference): the mx engine is held to the split-3 engine."""
+    from camouflaged_vlm_amd import spec, synth
+    from camouflaged_vlm_amd.engine import Precision, SamEncoder
+    g = spec.DEMO_SAM
+    dev = torch.device("cuda:0")
+    sd_np = synth.apply_outliers(synth.make_state_dict(spec.sam_encoder_entries(g)))
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+    inp = torch.from_numpy(synth.make_inputs(g, spec.DEMO_CLIP, batch=2)[0]).to(dev)
+    feats = {}
+    for name in ("exact", "mx"):
+        enc = SamEncoder(sd, g, dev, Precision.named(name))
+        feats[name] = enc.forward(inp).clone()
+        assert bool(torch.isfinite(feats[name]).all()) and enc.ws.gemm_errors() == 0
+        del enc
+        torch.cuda.empty_cache()
+    err = float((feats["mx"] - feats["exact"]).abs().max())
+    print(f"outlier weights, demo geometry, encoder features (LayerNorm2d output, O(1)): mx vs split-3 {err:.2e}")
+    assert err < 5e-4
+
+
+def test_mx_encoder_hires_1536_batch4(golden_dir):
+    """BASELINE configs[4] in this mode: model built at 1536^2, B = 4, all four images against the reference's digest."""
+    from camouflaged_vlm_amd import digest, spec, synth
+    from camouflaged_vlm_amd.engine import Precision, SamEncoder
+    with np.load(os.path.join(golden_dir, "hires1536_digest.npz")) as z:
+        dg = {k: z[k] for k in z.files}
+    g = dataclasses.replace(spec.DEMO_SAM, inp_size=1536)
+    dev = torch.device("cuda:0")
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_state_dict(spec.sam_encoder_entries(g)).items()}
+    enc = SamEncoder(sd, g, dev, Precision.named("mx"))
+    del sd
+    inp = torch.from_numpy(synth.make_inputs(g, spec.DEMO_CLIP, batch=4)[0]).to(dev)
+    f4 = enc.forward(inp).clone()
+    assert bool(torch.isfinite(f4).all())
+    r = digest.check_hires_features(f4, g.grid, dg, [0, 1, 2, 3])
+    print(f"mx, 1536^2 ViT-H encoder B=4 vs reference digest: {r}")
+    assert r["ok"] and r["checked_images"] == [0, 1, 2, 3] and r["max_abs_feature_err"] <= 5e-4
+    assert enc.ws.gemm_errors() == 0
