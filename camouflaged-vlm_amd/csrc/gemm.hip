@@ -95,7 +95,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     }
     if (g.a_mx || g.out_mx || g.res_mx) {
         // mx images (ABI 10): split-3, one problem, the LDS-staged epilogues; whole 64-column groups
-        if (g.split != 3 || conv || g.batch > 1 || g.ps_c2 > 0 || g.a_il || (g.out_mx && g.out_il) || (g.res_mx && g.res_il) ||
+        if (g.split != 3 || conv || g.batch > 1 || g.ps_c2 > 0 || (g.a_mx && g.a_il) || (g.out_mx && g.out_il) || (g.res_mx && g.res_il) ||
             (g.N & 7) || (g.ldoh & 7) || (g.stride_oh & 7) || (g.hm_S > 0 && ((g.hm_hd & 7) || g.hm_S < 256)) ||
             (g.out_f32 && ((g.ldo & 3) || (g.stride_o & 3))) || (g.residual && ((g.ldr & 3) || (g.stride_r & 3))))
             return CVLM_E_UNSUPPORTED;

@@ -1158,6 +1158,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                                 l8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8b, lv[3], s_lo, true);
                                 if (DBG == 3) { asm volatile("" ::"v"(hi), "v"(h8a), "v"(h8b), "v"(l8a), "v"(l8b)); continue; }
                                 unsigned char* row = (unsigned char*)g.out_hi + ((int64_t)m * g.ldoh + ((nh >> 6) << 7)) * 2;      // the 256-byte group
+                                if (DBG == 7) row = (unsigned char*)g.out_hi + tid * 256;     // probe: the same store instructions into 128 KB that stay in L2
                                 const int j8 = (nh & 63) >> 3;
                                 *(half8*)(row + j8 * 16) = hi;
                                 *(uint2*)(row + 128 + j8 * 8) = make_uint2(__builtin_bit_cast(unsigned, h8a), __builtin_bit_cast(unsigned, h8b));
@@ -1176,6 +1177,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                                 while (tk >= g.hm_S) { tk -= g.hm_S; ++bi; }
                                 off = hm_col + (int64_t)bi * hm_bstride + (int64_t)tk * g.hm_hd;
                             }
+                            if (DBG == 7) off = tid * 8;                   // probe: the same store instructions into a few KB that stay in L2
                             if (DBG == 3) {                                // probe: all the work, no global stores
                                 asm volatile("" ::"v"(hi), "v"(lo), "v"(off));
                             } else {

@@ -24,7 +24,10 @@ int cvlm_gemm_k::launch_mx(GemmParams& p, int mt, int epi, int extra_blocks, int
         switch (probe) {
             case 1: return launch_one<8, 1, 1>(p, extra_blocks, s);
             case 2: return launch_one<8, 1, 2>(p, extra_blocks, s);
+            case 3: return launch_one<8, 1, 3>(p, extra_blocks, s);
+            case 5: return launch_one<8, 1, 5>(p, extra_blocks, s);
             case 6: return launch_one<8, 1, 6>(p, extra_blocks, s);
+            case 7: return launch_one<8, 1, 7>(p, extra_blocks, s);
             case 9: return launch_one<8, 1, 9>(p, extra_blocks, s);
             case 10: return launch_one<8, 1, 10>(p, extra_blocks, s);
             case 11: return launch_one<8, 1, 11>(p, extra_blocks, s);

@@ -5,6 +5,7 @@ CLIP forward).  Prints microseconds per launch and algorithmic TFLOP/s.
     python tools/ab_gemm_mx.py            # PROBE=1: launches of the probe library named by CVLM_PROBE_LIB instead
 """
 import os, sys, time, torch
+os.environ["CVLM_GEMM_VARIANT_LIVE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from camouflaged_vlm_amd import hip as H
 H.load()
@@ -44,12 +45,13 @@ for name, M, N, K, form in shapes:
         stats = torch.zeros(H.stats_pieces(N), M, 2, device=dev)
         kw.update(row_stats=stats)
         outs = {"split3": r_il, "mx": r_mx}
-    res = {"split3": [], "mx": []}
+    modes = ["split3", "mx"]
+    res = {m: [] for m in modes}
     for rep in range(REPS):
-        for mode in ("split3", "mx"):
+        for mode in modes:
             a = A_il if mode == "split3" else A_mx
             k2 = dict(kw)
-            if mode == "mx":
+            if mode != "split3":
                 k2["w_mx"] = W_mx
             if form == "h2res":
                 k2["residual_h2"] = (outs[mode], 1.0)

@@ -9,12 +9,13 @@ from camouflaged_vlm_amd.engine import Cascade, Precision
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "mx"))
 ap.add_argument("--pipelined", action="store_true", help="the loop bench.py times: stage 2 of a batch fused with the next batch's CLIP pass 1 (one stream here)")
 a = ap.parse_args()
 g, c = spec.DEMO_SAM, spec.DEMO_CLIP
 dev = torch.device("cuda:0")
 sd = {k: torch.from_numpy(v) for k, v in synth.make_full_state_dict(g, c).items()}
-cas = Cascade(sd, g, c, dev, Precision.named("exact"))
+cas = Cascade(sd, g, c, dev, Precision.named(a.precision))
 cas.overlap_clip = False                        # one stream: per-launch event times need the kernels one at a time
 eot = host.eot_for_classes(host.ovcamo_constants()["names_test"].tolist())[:c.n_cls_test]
 cas.clip.set_text_bank(cas.clip.text_features(eot, "test"), torch.from_numpy(host.ovcamo_constants()["bank_test"]).float(), "test")
