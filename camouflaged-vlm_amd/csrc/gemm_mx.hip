@@ -38,6 +38,15 @@ int cvlm_gemm_k::launch_mx(GemmParams& p, int mt, int epi, int extra_blocks, int
             default: break;
         }
     }
+    if (mt == 8 && epi == 2) {                                            /* the h2-residual form (lin2): a few of the same probes */
+        switch (probe) {
+            case 1: return launch_one<8, 2, 1>(p, extra_blocks, s);
+            case 2: return launch_one<8, 2, 2>(p, extra_blocks, s);
+            case 3: return launch_one<8, 2, 3>(p, extra_blocks, s);
+            case 6: return launch_one<8, 2, 6>(p, extra_blocks, s);
+            default: break;
+        }
+    }
 #endif
     (void)probe;
     if (mt == 6 && epi == 2) return launch_one<6, 2, 0>(p, extra_blocks, s);

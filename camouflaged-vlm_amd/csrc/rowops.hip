@@ -241,6 +241,86 @@ __global__ __launch_bounds__(256) void row_stats_split_kernel(const float* __res
     }
 }
 
+// cvlm_row_stats_split with the rows written as an mx operand (include/cvlm.h ABI 10: image + block exponents + fp16 lo plane) -- the
+// CLIP tower's residual stream in the `mx` precision.  One wave per row, a lane owns 8 columns per pass: the four lanes of a 32-column
+// block are a DPP quad, as in the GEMM epilogue that writes the same format (gemm_kernel.h, out_mx), and the bytes are the same
+// (tests/test_gemm_mx_gpu.py holds both to hip.mx_pack).
+__global__ __launch_bounds__(256) void row_stats_split_mx_kernel(const float* __restrict__ x, float scale, unsigned char* __restrict__ img,
+                                                                 int64_t ld_img, unsigned char* __restrict__ sc, int64_t ld_s,
+                                                                 half_t* __restrict__ lo, int64_t ld_lo, float* __restrict__ stats, int M,
+                                                                 int D, int64_t dst_row_stride, int64_t stats_rows) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    typedef short s2v __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * D;
+    const int64_t drow = (int64_t)blockIdx.y * dst_row_stride + row;       // destination row of this copy
+    stats += 2 * (int64_t)blockIdx.y * dst_row_stride;
+    const int nchunk = D >> 3;
+    for (int c0 = 0; c0 < nchunk; c0 += 64) {                         // wave-uniform trip count: the exchanges need every lane
+        const int ch = c0 + lane;
+        const bool live = ch < nchunk;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        unsigned hi4[4] = {0u, 0u, 0u, 0u}, lo4[4] = {0u, 0u, 0u, 0u};
+        if (live) {
+            const float4 t0 = *(const float4*)(xr + ch * 8), t1 = *(const float4*)(xr + ch * 8 + 4);
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_h2_pk(v[2 * j] * scale, v[2 * j + 1] * scale, hi4[j], lo4[j]);
+        }
+        // block exponent: largest |hi| of the 32 columns (D % 64 == 0: a quad is live or dead as a whole)
+        h2v hv[4], lv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hv[j] = __builtin_bit_cast(h2v, hi4[j]); lv[j] = __builtin_bit_cast(h2v, lo4[j]); }
+        h2v mx2 = __builtin_elementwise_abs(hv[0]);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) mx2 = __builtin_elementwise_max(mx2, __builtin_elementwise_abs(hv[j]));
+        float bmax = fmaxf((float)mx2[0], (float)mx2[1]);
+        bmax = fmaxf(bmax, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bmax), 0xB1, 0xF, 0xF, true)));
+        bmax = fmaxf(bmax, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, bmax), 0x4E, 0xF, 0xF, true)));
+        int ex = (__builtin_bit_cast(int, bmax) >> 23) & 0xff;
+        ex = (ex < 103 ? 103 : ex) - 7;
+        const float s_hi = __builtin_bit_cast(float, ex << 23), s_lo = __builtin_bit_cast(float, (ex - 11) << 23);
+        if (live) {
+            s2v h8a = {0, 0}, h8b = {0, 0}, l8a = {0, 0}, l8b = {0, 0};
+            h8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8a, hv[0], s_hi, false);
+            h8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8a, hv[1], s_hi, true);
+            h8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8b, hv[2], s_hi, false);
+            h8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(h8b, hv[3], s_hi, true);
+            l8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8a, lv[0], s_lo, false);
+            l8a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8a, lv[1], s_lo, true);
+            l8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8b, lv[2], s_lo, false);
+            l8b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(l8b, lv[3], s_lo, true);
+            const int n = ch * 8, j8 = (n & 63) >> 3;
+            unsigned char* grp = img + (drow * ld_img + ((n >> 6) << 7)) * 2;                 // the 256-byte group of these columns
+            *(uint4*)(grp + j8 * 16) = make_uint4(hi4[0], hi4[1], hi4[2], hi4[3]);
+            *(uint2*)(grp + 128 + j8 * 8) = make_uint2(__builtin_bit_cast(unsigned, h8a), __builtin_bit_cast(unsigned, h8b));
+            *(uint2*)(grp + 192 + j8 * 8) = make_uint2(__builtin_bit_cast(unsigned, l8a), __builtin_bit_cast(unsigned, l8b));
+            if ((lane & 3) == 0) {
+                unsigned char* e = sc + (drow * 4 + (j8 >> 2)) * ld_s + (n >> 6);
+                e[0] = (unsigned char)ex;
+                e[2 * ld_s] = (unsigned char)(ex - 11);
+            }
+            *(uint4*)(lo + drow * ld_lo + n) = make_uint4(lo4[0], lo4[1], lo4[2], lo4[3]);
+        }
+        const int piece = ch >> 3;
+        const int np = D - piece * 64 < 64 ? D - piece * 64 : 64;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += v[j];
+        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+        const float pm = s1 * (np == 64 ? 0.015625f : 1.0f / (float)(np > 0 ? np : 1));
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - pm; s2 = fmaf(d, d, s2); }
+        }
+        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+        if (live && (lane & 7) == 0) *(float2*)(stats + 2 * ((int64_t)piece * stats_rows + row)) = make_float2(s1, s2);
+    }
+}
+
+
 // Piece statistics -> the (rstd, mu * rstd) pair per row the LayerNorm-folded GEMM epilogue reads (include/cvlm.h).  One thread per
 // row; the pieces of a row are added in index order (bit-reproducible), as centred moments:
 //   mu = sum_p s1_p / D,   M2 = sum_p [ m2_p + n_p (s1_p / n_p - mu)^2 ],   rstd = 1 / sqrt(M2 / D + eps).
@@ -678,6 +758,20 @@ int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo
     if (stats_rows < M + (int64_t)(copies - 1) * dst_row_stride) return CVLM_E_BADARG;
     hipLaunchKernelGGL(row_stats_split_kernel, dim3((M + 3) / 4, copies), dim3(256), 0, (hipStream_t)stream, x, scale, (half_t*)out_hi,
                        (half_t*)out_lo, stats, M, D, dst_row_stride, stats_rows);
+    CVLM_CHECK_LAUNCH();
+    return 0;
+}
+
+int cvlm_row_stats_split_mx(const float* x, float scale, void* out_img, int64_t ld_img, void* out_scales, int64_t ld_s, void* out_lo,
+                            int64_t ld_lo, float* stats, int64_t stats_rows, int32_t M, int32_t D, int32_t copies, int64_t dst_row_stride,
+                            void* stream) {
+    if (!x || !out_img || !out_scales || !out_lo || !stats || M <= 0 || D <= 0 || (D & 63) || copies < 1 || copies > 65535) return CVLM_E_BADARG;
+    if (ld_img < 2 * (int64_t)D || (ld_img & 7) || ld_s * 64 < D || (ld_lo & 7) || ld_lo < D) return CVLM_E_BADARG;
+    if (copies > 1 && dst_row_stride < M) return CVLM_E_BADARG;
+    if (stats_rows < M + (int64_t)(copies - 1) * dst_row_stride) return CVLM_E_BADARG;
+    hipLaunchKernelGGL(row_stats_split_mx_kernel, dim3((M + 3) / 4, copies), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       (unsigned char*)out_img, ld_img, (unsigned char*)out_scales, ld_s, (half_t*)out_lo, ld_lo, stats, M, D,
+                       dst_row_stride, stats_rows);
     CVLM_CHECK_LAUNCH();
     return 0;
 }

@@ -447,6 +447,7 @@ class SamEncoder(_Base):
         if use_mx:
             x_last = xo
             xo = ws.h2mx("xh_mx", M, D, lo_plane=True)
+            # (lin2 on split-3 operands -- hidden rows as the 128-byte-row image -- measured 0.7 % slower per step, mask 1.7e-4 instead of 2.1e-4)
             hid = ws.h2mx("hid_mx", M, HK)
             hid_prm = hid.cols(g.mlp_dim)
         hk = {} if use_il else {"ldoh": HK}                          # the image carries its own row stride
@@ -928,9 +929,9 @@ class ClipModel(_Base):
             for i, blk in enumerate(self.vblocks):
                 p = f"{ie}transformer.resblocks.{i}."
                 blk["inp_f"] = LnLinear(sd[p + "attn.in_proj.weight"], sd[p + "attn.in_proj.bias"],
-                                        sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], device)
+                                        sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], device, mx=precision.mx)
                 blk["fc_f"] = LnLinear(sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"],
-                                       sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], device)
+                                       sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], device, mx=precision.mx)
         self.tblocks = [block(f"{te}transformer.resblocks.{i}.", True) for i in range(c.text_layers)]
         self.tpos = self.dev(sd[te + "positional_embedding"])
         self.ln_final = (self.dev(sd[te + "ln_final.weight"]), self.dev(sd[te + "ln_final.bias"]))
@@ -987,10 +988,14 @@ class ClipModel(_Base):
             and pr.gemm == 3 and (4 * Wd) % 32 == 0 and all(b["pj"].w_il is not None and b["fc_f"].w_il is not None for b in self.vblocks)
         hid = ws.h2il("vhid_il", M, 4 * Wd) if hid_il else ws.h2("vhid", M, 4 * Wd)
         # precision `mx`: the hidden rows as an mx operand (SamEncoder._blocks_folded): c_proj, a third of the tower's GEMM flops, runs
-        # its two correction products on the block-scaled e4m3 instruction.  (in_proj / c_fc read the residual stream, whose planes the
-        # deep prompts overwrite row by row: it stays in planes.)
+        # its two correction products on the block-scaled e4m3 instruction
         if hid_il and pr.mx and (4 * Wd) % 64 == 0 and M % 8 == 0 and all(b["pj"].w_mx is not None for b in self.vblocks):
             hid = ws.h2mx("vhid_mx", M, 4 * Wd)
+            # ... and the residual stream itself (image + block exponents + lo plane: cvlm_row_stats_split_mx seeds it and writes the
+            # deep prompts' rows into it; out_proj / c_proj write it back): in_proj and c_fc, the other half of the tower's GEMM
+            # flops, read mx operands too.  Needs the class-token tail (the last block reads the stream by its class rows).
+            if Wd % 64 == 0 and self.class_token_tail and all(b["inp_f"].w_mx is not None and b["fc_f"].w_mx is not None for b in self.vblocks):
+                xh = ws.h2mx("vxh_mx", M, Wd, lo_plane=True)
         pcs, mrg = ws.f32("vln_pieces", hip.stats_pieces(Wd), M, 2), ws.f32("vln_merged", M, 2)
         gws = self.ws.gemm_ws()
         hip.row_stats_split(x.view(M, Wd), X_SCALE, xh, pcs, M, Wd)
@@ -1025,7 +1030,8 @@ class ClipModel(_Base):
         self.attention(qkv, att, Bn, L, heads, Wd // heads, mode=0, causal=False, split_qk=pr.qk, split_pv=pr.pv, q_rows=1)
         xc, hidc = ws.h2("vx_cls", Bn, Wd), ws.h2("vhid_cls", Bn, 4 * Wd)
         pcs, mrg = ws.f32("vln_pieces_cls", hip.stats_pieces(Wd), Bn, 2), ws.f32("vln_merged_cls", Bn, 2)
-        self.gemm(att, blk["out"], Bn, lda=L * Wd, out_h2=xc, residual_h2=(xh, inv), ldrh=L * Wd, out_scale=X_SCALE, row_stats=pcs)
+        res = (xh.every(L), inv) if getattr(xh, "mx", False) else (xh, inv)       # the class rows of the stream (an mx stream: a strided view)
+        self.gemm(att, blk["out"], Bn, lda=L * Wd, out_h2=xc, residual_h2=res, ldrh=L * Wd, out_scale=X_SCALE, row_stats=pcs)
         hip.ln_stats_merge(pcs, Bn, Wd, 1e-5, mrg, gws)
         self.gemm(xc, blk["fc_f"], Bn, out_h2=hidc, act=ACT_QUICKGELU, out_scale=HID_SCALE, alpha=inv, ln_fold=(mrg, blk["fc_f"].colsum))
         self.gemm(hidc, blk["pj"], Bn, out_h2=xc, residual_h2=(xc, inv), out_scale=X_SCALE, alpha=1.0 / HID_SCALE)

@@ -23,7 +23,7 @@ EXPORTS = [
     "cvlm_dense_pe", "cvlm_mask_head", "cvlm_bilinear", "cvlm_clip_assemble", "cvlm_overwrite_rows",
     "cvlm_gather_rows", "cvlm_clip_head", "cvlm_normalize_add", "cvlm_resample_u8", "cvlm_u8_to_tensor",
     "cvlm_mask_to_u8", "cvlm_mask_joint_hist", "cvlm_mask_wfm", "cvlm_topk_accumulate",
-    "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_gather_rows_h2",
+    "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_row_stats_split_mx", "cvlm_gather_rows_h2",
     "cvlm_ln_stats_merge", "cvlm_small_attention_h2", "cvlm_prob_quantise", "cvlm_prob_moments", "cvlm_prob_wfm",
 ]
 ABI_VERSION = 10
@@ -218,6 +218,11 @@ class H2MX:
         """The operand that starts at column c0 (c0 % 64 == 0): same rows, same pitches."""
         assert c0 % 64 == 0 and self.lo is None
         return H2MX(self.t, self.s, None, self.C - c0, self.c0 + c0)
+
+    def every(self, step: int) -> "H2MX":
+        """Rows 0, step, 2 * step, ... as an operand of their own (views: same memory, `step` times the row pitches) -- the class-token
+        rows of a [B * L]-row stream."""
+        return H2MX(self.t[::step], self.s[::step], None if self.lo is None else self.lo[::step], self.C, self.c0)
 
     def data_ptr(self) -> int:
         return self.t.data_ptr() + 4 * self.c0
@@ -414,6 +419,15 @@ def row_stats_split(x: torch.Tensor, scale: float, out: H2, stats: torch.Tensor,
     """out rows [row0 + c * dst_row_stride + m] = x[m] * scale as h2; stats f32 [pieces][rows][2] gets the piece statistics of the
     same rows (sum, centred sum of squares per 64 columns of the unscaled row)."""
     assert stats.dim() == 3 and stats.shape[0] == stats_pieces(D) and stats.shape[2] == 2 and stats.is_contiguous()
+    if getattr(out, "mx", False):                                     # the rows as an mx operand (image + block exponents + lo plane), ABI 10
+        assert out.lo is not None and out.c0 == 0 and out.C == D
+        _check(load().cvlm_row_stats_split_mx(
+            C.c_void_p(x.data_ptr()), C.c_float(scale), C.c_void_p(out.t.data_ptr() + row0 * out.t.stride(0)), C.c_int64(out.t.stride(0) // 2),
+            C.c_void_p(out.s.data_ptr() + row0 * out.s.stride(0)), C.c_int64(out.s.stride(1)),
+            C.c_void_p(out.lo.data_ptr() + 2 * row0 * out.lo.stride(0)), C.c_int64(out.lo.stride(0)), C.c_void_p(stats.data_ptr() + 8 * row0),
+            C.c_int64(stats.shape[1]), C.c_int32(M), C.c_int32(D), C.c_int32(copies), C.c_int64(dst_row_stride), C.c_void_p(_stream())),
+            "cvlm_row_stats_split_mx")
+        return
     _check(load().cvlm_row_stats_split(C.c_void_p(x.data_ptr()), C.c_float(scale), C.c_void_p(out.hi.data_ptr() + 2 * row0 * D),
                                        C.c_void_p(out.lo.data_ptr() + 2 * row0 * D), C.c_void_p(stats.data_ptr() + 8 * row0),
                                        C.c_int64(stats.shape[1]), C.c_int32(M), C.c_int32(D), C.c_int32(copies),

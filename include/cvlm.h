@@ -173,6 +173,13 @@ int cvlm_ln_stats_merge(const float* pieces, int64_t piece_rows, int32_t M, int3
  * (alpha_clip_rw/model.py:392-434) on an h2 stream: out = planes + first_row * D, stats + 2 * first_row, stride = L. */
 int cvlm_row_stats_split(const float* x, float scale, void* out_hi, void* out_lo, float* stats, int64_t stats_rows, int32_t M,
                          int32_t D, int32_t copies, int64_t dst_row_stride, void* stream);
+/* ABI 10: the same with the rows written as an mx operand (cvlm_gemm_args above: image `out_img` with row stride ld_img halves, block
+ * exponents `out_scales` [rows][4][ld_s], fp16 lo plane `out_lo` [rows][ld_lo]); D % 64 == 0.  The pointers address the first
+ * destination row.  Seeds (and, for the deep prompts, overwrites rows of) the CLIP tower's residual stream when that stream is an mx
+ * operand of the LayerNorm-folded in_proj / c_fc GEMMs (alpha_clip_rw/model.py:392-434, 296-300). */
+int cvlm_row_stats_split_mx(const float* x, float scale, void* out_img, int64_t ld_img, void* out_scales, int64_t ld_s, void* out_lo,
+                            int64_t ld_lo, float* stats, int64_t stats_rows, int32_t M, int32_t D, int32_t copies, int64_t dst_row_stride,
+                            void* stream);
 
 /* f32 -> h2 planes (elementwise split), n elements.  No reference counterpart: it produces the operand format of
  * cvlm_gemm / cvlm_attention from tensors the reference keeps in fp32 (e.g. the sparse prompts, models/sam_maskdecoder_edge.py:342-344). */

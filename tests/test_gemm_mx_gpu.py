@@ -227,6 +227,39 @@ def test_mx_pack_on_the_device_equals_the_host(hip):
 
 
 @pytest.mark.gpu
+def test_row_stats_split_mx_writes_mx_pack_of_the_planes(hip):
+    """cvlm_row_stats_split_mx (the CLIP stream's seed and its deep-prompt rows): image, exponents, lo plane and piece statistics ==
+    those of the planar kernel, through mx_pack -- whole tensor and `copies` rows dropped into a larger stream."""
+    dev = "cuda"
+    M, D = 581 * 2, 1024
+    x = rnd(M, D, seed=31)
+    x[:, 9] *= 400.0
+    x[5] *= 1e-3
+    ref, st_ref = H.H2.empty(M, D, device=dev), torch.zeros(H.stats_pieces(D), M, 2, device=dev)
+    hip.row_stats_split(x.to(dev), 0.25, ref, st_ref, M, D)
+    out, st = H.H2MX.empty(M, D, device=dev, lo_plane=True), torch.zeros(H.stats_pieces(D), M, 2, device=dev)
+    hip.row_stats_split(x.to(dev), 0.25, out, st, M, D)
+    torch.cuda.synchronize()
+    img, sc = H.mx_pack(H.H2(ref.t.cpu()))
+    assert torch.equal(out.t.cpu().view(M, -1, 256), img) and torch.equal(out.s.cpu()[:, :, :D // 64], sc[:, :, :D // 64])
+    assert torch.equal(out.lo.cpu(), ref.t[1].cpu()) and torch.equal(st, st_ref)
+    # four prompt rows written into rows 577..580 of both images (copies = 2, stride = 581 rows): nothing else moves
+    p4 = rnd(4, D, seed=32).to(dev)
+    before_t, before_s, before_lo = out.t.clone(), out.s.clone(), out.lo.clone()
+    hip.row_stats_split(p4, 0.25, out, st, 4, D, row0=577, copies=2, dst_row_stride=581)
+    hip.row_stats_split(p4, 0.25, ref, st_ref, 4, D, row0=577, copies=2, dst_row_stride=581)
+    torch.cuda.synchronize()
+    img, sc = H.mx_pack(H.H2(ref.t.cpu()))
+    assert torch.equal(out.t.cpu().view(M, -1, 256), img) and torch.equal(out.s.cpu()[:, :, :D // 64], sc[:, :, :D // 64])
+    assert torch.equal(out.lo.cpu(), ref.t[1].cpu()) and torch.equal(st, st_ref)
+    rows = torch.ones(M, dtype=torch.bool)
+    rows[577:581] = False
+    rows[581 + 577:581 + 581] = False
+    assert torch.equal(out.t[rows.to(dev)], before_t[rows.to(dev)]) and torch.equal(out.s[rows.to(dev)], before_s[rows.to(dev)])
+    assert torch.equal(out.lo[rows.to(dev)], before_lo[rows.to(dev)])
+
+
+@pytest.mark.gpu
 def test_gemm_mx_argument_checks(hip):
     dev = "cuda"
     M, N, K = 512, 256, 128
