@@ -445,6 +445,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
                 }
             }
             p.group_m = g.K >= 4096 ? 2 : 4;
+            if (live_env && env_int("CVLM_GEMM_GROUP_M", 0) > 0) p.group_m = env_int("CVLM_GEMM_GROUP_M", 0);   /* tools only */
             const int probe = variant_env >= 100 ? variant_env - 100 : 0;          /* probe builds: tools/probe_gemm_mx.py */
             return launch_mx(p, use192 ? 6 : 8, fold ? 1 : (h2res ? 2 : 0), extra_blocks, probe, s);
         }

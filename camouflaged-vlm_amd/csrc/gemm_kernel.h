@@ -568,7 +568,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     }
                     acc[mh * MH + mt][nt] = c;
                 }
-                if (dma) dma_batch(k, (mt * PER_WAVE) / MH, ((mt + 1) * PER_WAVE) / MH);
+                // the weight pieces (one unit to land) all go out behind the first m-tile, the activation pieces (two units) behind the others
+                if (dma) {
+                    if (MH >= 2) dma_batch(k, mt == 0 ? 0 : PW_W + ((mt - 1) * PW_A) / (MH - 1), mt == 0 ? PW_W : PW_W + (mt * PW_A) / (MH - 1));
+                    else dma_batch(k, 0, PER_WAVE);
+                }
             }
         };
         auto kind_of = [](auto r_c) { constexpr int R = decltype(r_c)::value; return std::integral_constant<int, (R & 1) ? 1 + (R >> 1) : 0>{}; };

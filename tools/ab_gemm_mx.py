@@ -45,10 +45,13 @@ for name, M, N, K, form in shapes:
         stats = torch.zeros(H.stats_pieces(N), M, 2, device=dev)
         kw.update(row_stats=stats)
         outs = {"split3": r_il, "mx": r_mx}
-    modes = ["split3", "mx"]
+    gms = [int(x) for x in os.environ.get("GROUP_MS", "").split(",") if x]          # CVLM_GEMM_GROUP_M values to race (tile rows per L2 super-tile)
+    modes = ["split3", "mx"] + ["mx gm %d" % k for k in gms]
+    outs.update({m: outs["mx"] for m in modes[2:]})
     res = {m: [] for m in modes}
     for rep in range(REPS):
         for mode in modes:
+            os.environ["CVLM_GEMM_GROUP_M"] = mode.split()[-1] if " gm " in mode else "0"
             a = A_il if mode == "split3" else A_mx
             k2 = dict(kw)
             if mode != "split3":
