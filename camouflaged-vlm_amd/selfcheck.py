@@ -44,3 +44,19 @@ def smoke() -> None:
     print(f"smoke: max|mask - oracle| = {dm:.2e}, max|logits - oracle| = {dl:.2e}, IoU = {iou:.6f}, "
           f"pred {pred.cpu().tolist()} vs {p_ref.tolist()}")
     assert dm < 1e-3 and dl < 1e-3 and iou >= 0.999 and pred.cpu().tolist() == p_ref.tolist()
+    # The tiny geometry (D = 160) has no mx launches (K % 64 != 0): one launch of the mx GEMM form the demo geometry's default precision
+    # runs on -- mx operands in, h2 residual epilogue, mx out -- against the fp64 product of the same h2 values.
+    from . import hip
+    M, N, K = 512, 256, 256
+    gen = torch.Generator().manual_seed(3)
+    a, w, r = (torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) * K ** -0.5, torch.randn(M, N, generator=gen))
+    ap, wp, rp = hip.H2.pack(a), hip.H2.pack(w), hip.H2.pack(r)
+    mv = lambda m: hip.H2MX(m.t.to(dev), m.s.to(dev), None if m.lo is None else m.lo.to(dev), m.C)
+    out = mv(hip.H2MX.from_planes(rp, lo_plane=True))
+    hip.gemm(mv(hip.H2MX.from_planes(ap)), hip.H2(wp.t.to(dev)), M, N, K, out_h2=out, residual_h2=(out, 1.0), w_mx=mv(hip.H2MX.from_planes(wp)))
+    torch.cuda.synchronize()
+    want = ap.float().double() @ wp.float().double().t() + rp.float().double()
+    got = out.hi().float().cpu().double() + out.lo.float().cpu().double()
+    dg = float((got - want).abs().max() / want.abs().max())
+    print(f"smoke: mx GEMM {M}x{N}x{K} (f16 hi.hi + e4m3 corrections) vs fp64: {dg:.2e} of the largest output")
+    assert dg < 1e-4
