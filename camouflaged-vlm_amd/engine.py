@@ -441,7 +441,10 @@ class SamEncoder(_Base):
         # products on the block-scaled e4m3 instruction.  The stream keeps its fp16 lo plane beside the image: proj / lin2 read and
         # write it as their h2 residual at full 22 bits.  Block 0's qkv still reads the planar seed; the last lin2 writes the
         # 128-byte-row image the neck reads.
-        use_mx = (use_il and pr.mx and D % 64 == 0 and HK % 64 == 0 and self.blocks[-1]["lin2"].w_mx is not None and
+        # One image per call (M <= 4096, the reference's own call pattern) stays on split-3 operands: the mx kernel has only its 256-row
+        # tile form, the small-grid forms of the split-3 launcher (column split, K-parts, deep rings) are as fast there (24.2 ms per image
+        # either way, profiles/r05_per_shape_times_b1.log) and keep the 3e-5 of the `exact` arithmetic.
+        use_mx = (use_il and pr.mx and M > 4096 and D % 64 == 0 and HK % 64 == 0 and self.blocks[-1]["lin2"].w_mx is not None and
                   all(b["qkv_f"].w_mx is not None and b["lin1_f"].w_mx is not None for b in self.blocks) and
                   all(l.w_mx is not None for l in self.lin2cat))
         if use_mx:

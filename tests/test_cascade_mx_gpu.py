@@ -16,7 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 MX_MASK_TOL, MX_LOGIT_TOL, MX_IOU = 5e-4, 2.5e-4, 0.9999
-BATCH_TOL = 2e-4            # a batch against its single-image forwards in this mode (K-parts and tile forms differ with M)
+BATCH_TOL = 3e-4            # a batch (mx operands) against a single-image forward (M = 4096: split-3 operands, engine.SamEncoder._blocks_folded)
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +59,7 @@ def test_mx_mode_runs_the_mx_kernels(demo_mx):
         return orig(a, w, M, N, K, **kw)
     hip.gemm = spy
     try:
-        inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=1))
+        inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=2))
         cas.cascade(inp, ci, cm)
     finally:
         hip.gemm = orig
