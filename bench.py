@@ -196,7 +196,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "mx"), choices=["mx", "exact", "mixed", "fast"])
+    ap.add_argument("--precision", default=os.environ.get("CVLM_PRECISION", "mx"), choices=["mx", "mx33", "exact", "mixed", "fast"])
     ap.add_argument("--geometry", default="demo", choices=["demo", "tiny", "hires1536"])
     ap.add_argument("--workload", default="cascade", choices=["cascade", "encoder"],
                     help="encoder = SAM ViT-H image encoder only (BASELINE configs[1] / [4] with --geometry hires1536)")
@@ -297,8 +297,8 @@ def cpu_model() -> str:
 
 
 DTYPE_NAMES = {"exact": "f32-grade (3x f16 split MFMA, f32 accumulate)",
-               "mx": "f32-grade (f16 hi.hi MFMA + block-scaled e4m3 MFMA for the two correction products in the ViT-H qkv / lin1 / lin2 GEMMs, "
-                     "3x f16 split elsewhere; f32 accumulate)", "mixed": "f32-grade GEMM/QK, f16 PV",
+               "mx": "f32-grade (f16 hi.hi MFMA + block-scaled e4m3 MFMA for the two correction products in the ViT-H qkv / lin1 / lin2 and CLIP MLP "
+                     "GEMMs, 2x f16 in the ViT-H attention products, 3x f16 split elsewhere; f32 accumulate)", "mx33": "f32-grade (as mx, 3x f16 in the attention products)", "mixed": "f32-grade GEMM/QK, f16 PV",
                "fast": "f16 operands, f32 accumulate"}
 
 
@@ -341,7 +341,7 @@ class Roofline:
                 G = kw["grid"]
                 nw = -(-G // w)
                 fl = 4.0 * (w * w) ** 2 * hd * heads * Bn * nw * nw
-            arecs["global" if mode == 1 else "window"].append((fl, e0, e1, S))
+            arecs["global" if mode == 1 else "window"].append((fl, e0, e1, S, min(kw.get("split_qk", 3), kw.get("split_pv", 3))))
 
         hip.gemm, hip.attention = timed_gemm, timed_attn
         return self
@@ -376,14 +376,15 @@ class Roofline:
                     "window": "attn_win14p_kernel (ViT-H 14x14 window attention, producer / consumer form)"}[name]
             f_, m_ = sum(r[0] for r in rs), sum(r[1].elapsed_time(r[2]) for r in rs)
             tf = f_ / (m_ * 1e-3) / 1e12
-            issued_factor = float(self.split)               # P.V runs on 16-wide output tiles since round 3: no padding of head dim 80
+            issued_factor = float(rs[0][4])                 # MFMAs per product: 3 (hi/lo on both sides) or 2 (split 2: no lo planes of Q and P); no padding of head dim 80
             secondary.append({"kernel": kern, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(tf / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                               "issued": round(tf * issued_factor, 1), "frac_issued": round(tf * issued_factor / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                               "launches": len(rs), "avg_launch_us": round(1e3 * m_ / len(rs), 2),
                               "algorithmic_gflop_per_launch": round(f_ / len(rs) / 1e9, 3),
-                              "note": "achieved / frac: algorithmic FLOPs (4*S^2*hd per head, SURVEY.md §8d); issued: the MFMA flops the "
-                                      "exact mode executes for them (3 f16 products per multiply; round 2 also padded head dim 80 to 96 in P.V)"})
+                              "products_per_multiply": rs[0][4],
+                              "note": "achieved / frac: algorithmic FLOPs (4*S^2*hd per head, SURVEY.md §8d); issued: the f16 MFMA flops executed "
+                                      "for them (3 per multiply with hi/lo operands on both sides, 2 in precision mx: K and V keep their lo planes)"})
         mx_flops = sum(r[0] for r in records if r[4])
         mx_ms = sum(r[1].elapsed_time(r[2]) for r in records if r[4])
         # matrix-pipe work in f16-MFMA equivalents: a split-3 launch issues 3 f16 products per multiply, an mx launch 1 f16 product + 2 e4m3

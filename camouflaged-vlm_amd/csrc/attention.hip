@@ -385,7 +385,8 @@ int launch(const AttnParams& p, hipStream_t s) {
 template <int HD, int NW, int MODE, bool CAUSAL>
 int launch_split(const AttnParams& p, hipStream_t s) {
     const int sq = p.a.split_qk, sp = p.a.split_pv;
-    if (sq == 3 && sp == 3) return launch<HD, NW, MODE, 3, 3, CAUSAL>(p, s);
+    // split 2 (include/cvlm.h) has kernels for the ViT-H geometries only: everywhere else it runs as split 3, which holds its products and more
+    if ((sq == 3 && sp == 3) || (sq == 2 && sp == 2)) return launch<HD, NW, MODE, 3, 3, CAUSAL>(p, s);
     if (sq == 3 && sp == 1) return launch<HD, NW, MODE, 3, 1, CAUSAL>(p, s);
     if (sq == 1 && sp == 1) return launch<HD, NW, MODE, 1, 1, CAUSAL>(p, s);
     return CVLM_E_UNSUPPORTED;
@@ -393,8 +394,8 @@ int launch_split(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-// The two ViT-H kernels of the parity mode (split 3 on both products): every other precision, window size and map size runs the
-// generic kernel of this file.  (Rounds 1-4 also built a single-group global kernel and a two-workgroups-per-pair window kernel for
+// The two ViT-H kernels of the parity modes (split 3 or split 2 on both products): every other precision, window size and map size runs
+// the generic kernel of this file.  (Rounds 1-4 also built a single-group global kernel and a two-workgroups-per-pair window kernel for
 // the non-parity precisions: they carried no headline and left the build in round 5.)
 int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s);    // attention_g64pp.hip: 64 x 64 and 96 x 96 maps
 int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s);    // attention_win2.hip: 14 x 14 windows, h2 output
@@ -410,7 +411,7 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!args || !args->qkv_hi || !args->out_hi) return CVLM_E_BADARG;
     const cvlm_attn_args& g = *args;
     if (g.B <= 0 || g.S <= 0 || g.heads <= 0 || g.q_rows < 0 || (g.q_rows > 0 && g.mode != 0)) return CVLM_E_BADARG;
-    if ((g.split_qk == 3 || g.split_pv == 3) && !g.qkv_lo) return CVLM_E_BADARG;
+    if ((g.split_qk >= 2 || g.split_pv >= 2) && !g.qkv_lo) return CVLM_E_BADARG;
     AttnParams p;
     p.a = g;
     p.D = g.heads * g.hd;
@@ -421,10 +422,10 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
         return g.causal ? launch_split<64, 4, 0, true>(p, s) : launch_split<64, 4, 0, false>(p, s);
     }
     if (g.hd != 80 || g.causal) return CVLM_E_UNSUPPORTED;
-    if (!g.relh_hi || !g.relw_hi || (g.split_qk == 3 && (!g.relh_lo || !g.relw_lo))) return CVLM_E_BADARG;
+    if (!g.relh_hi || !g.relw_hi || (g.split_qk >= 2 && (!g.relh_lo || !g.relw_lo))) return CVLM_E_BADARG;
     if (g.grid <= 0 || g.S != g.grid * g.grid) return CVLM_E_BADARG;
     if (g.mode == 1) {
-        if ((g.grid == 64 || g.grid == 96) && g.split_qk == 3 && g.split_pv == 3) {   // 1024^2 / 1536^2 SAM geometries, parity mode
+        if ((g.grid == 64 || g.grid == 96) && g.split_qk == g.split_pv && g.split_qk >= 2) {   // 1024^2 / 1536^2 SAM geometries, parity modes
             const int rc = cvlm_attention_global64_pp(g, s);
             if (rc != CVLM_E_UNSUPPORTED) return rc;                           // incl. CVLM_E_WORKSPACE: a missing workspace is an error, not a silent fallback
         }
@@ -432,8 +433,8 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
         return launch_split<80, 4, 1, false>(p, s);
     }
     if (g.mode == 2) {
-        if (g.window <= 0 || !g.pad_hi || ((g.split_qk == 3 || g.split_pv == 3) && !g.pad_lo)) return CVLM_E_BADARG;
-        if (g.window == 14 && g.split_qk == 3 && g.split_pv == 3 && g.out_lo) return cvlm_attention_window14_pc(g, s);   // SAM window geometry, parity mode
+        if (g.window <= 0 || !g.pad_hi || ((g.split_qk >= 2 || g.split_pv >= 2) && !g.pad_lo)) return CVLM_E_BADARG;
+        if (g.window == 14 && g.split_qk == g.split_pv && g.split_qk >= 2 && g.out_lo) return cvlm_attention_window14_pc(g, s);   // SAM window geometry, parity modes
         p.L = g.window; p.LTP = g.window | 1;
         p.nwx = (g.grid + g.window - 1) / g.window;
         p.S_seq = g.window * g.window;

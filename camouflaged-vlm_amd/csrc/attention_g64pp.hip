@@ -27,7 +27,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CVLM_G64_PD
 #define CVLM_G64_PD 3
 #endif
-
 // phase-time probe (tools/trace_attn_g64.py): per wave 8 x u64 {prologue, sum X, sum X-side wait+barrier, sum Y, sum Y-side wait+barrier, total}
 __device__ unsigned long long* g_g64_trace = nullptr;
 
@@ -37,6 +36,12 @@ __device__ __forceinline__ half4 lds_read_tr16(const half_t* p) {
     return __builtin_bit_cast(half4, r);
 }
 
+// A operand of sixteen rows of ones: the 16x16x32 product ones . P^T puts the sum over a tile's 32 keys of the fp16 probabilities the P.V
+// product really multiplies with in every row -- the softmax denominator of the form that keeps one fp16 per probability (PLO == false)
+__device__ __forceinline__ half8 ones8() {
+    const half_t o = (half_t)1.0f;
+    return half8{o, o, o, o, o, o, o, o};
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void phase_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -44,7 +49,10 @@ __device__ __forceinline__ void phase_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int L>
+// PLO / QLO: the lo planes of P and of Q take part in their products (cvlm_attn_args.split_pv / split_qk == 3); false: two MFMAs per product,
+// P as ONE fp16 per probability (rounded to nearest, the softmax denominator summed from the rounded values by a ones-row product), Q
+// as its hi plane (split == 2: see include/cvlm.h)
+template <int L, bool PLO, bool QLO>
 __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
                                                             const half_t* __restrict__ vt_lo) {
     // L = side of the token map (64: 1024^2 images, 96: 1536^2).  A key row is TPR = L / 32 tiles; the 96 map needs a
@@ -193,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
     for (int n = 0; n < NDB; ++n)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) o[n][qb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 osum[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};   // !PLO: row sums of the ROUNDED probabilities (see ones8)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 xh[2] = {}, xl[2] = {};                                    // P^T as B operands of the 16x16x32 shape, per query block
     // V^T fragment of this lane: row (lane & 15) of a 16-row block, key group lane >> 4; position swizzled like the DMA image
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+            if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
         }
     };
     // Y(t): O^T += V(t)^T . P^T (five 16-dim blocks, six 16x16x32 MFMAs each), then S^T = K(t+1) . Q^T (five k-steps, three
@@ -239,9 +248,10 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     const half8 bh = __builtin_bit_cast(half8, xh[qb]), bl = __builtin_bit_cast(half8, xl[qb]);
+                    if constexpr (!PLO && I == 0) osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8(), bh, osum[qb], 0, 0, 0);
                     o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[I][qb], 0, 0, 0);
                     o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[I][qb], 0, 0, 0);
-                    o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[I][qb], 0, 0, 0);
+                    if constexpr (PLO) o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[I][qb], 0, 0, 0);
                 }
             } else {
                 constexpr int ks = I - NDB;
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
                 }
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s, 0, 0, 0);
+                if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s, 0, 0, 0);
             }
         };
         load(std::integral_constant<int, 0>{});
@@ -301,19 +311,26 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
 #pragma unroll
             for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
+            osum[0] *= a0; osum[1] *= a1;
         }
         m_run = m_new;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {                                // first / last eight values -> the two B operands (see attn_g64pair_kernel)
             const f32x2 v0 = z[p], v1 = z[4 + p];
-            const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
-            const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
-            const unsigned l0 = split_lo_pk(h0, v0.x, v0.y);
-            const unsigned l1 = split_lo_pk(h1, v1.x, v1.y);
+            unsigned h0, h1;
+            if constexpr (PLO) {
+                h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
+                h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
+                const unsigned l0 = split_lo_pk(h0, v0.x, v0.y);
+                const unsigned l1 = split_lo_pk(h1, v1.x, v1.y);
+                const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+                xl[0][p] = (unsigned)rl[0]; xl[1][p] = (unsigned)rl[1];
+            } else {                                                 // one fp16 per probability, rounded to nearest
+                h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, half2v));
+                h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, half2v));
+            }
             const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
-            const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
             xh[0][p] = (unsigned)rh[0]; xh[1][p] = (unsigned)rh[1];
-            xl[0][p] = (unsigned)rl[0]; xl[1][p] = (unsigned)rl[1];
         }
     };
 
@@ -359,10 +376,15 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
     }
     if (!grpB) phase_barrier();                                      // match B's extra leading barrier
 
-    const float l_tot = half_swap_sum(l_run);
-    const float inv = 1.0f / l_tot;
-    const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
-    const float invq[2] = {__builtin_bit_cast(float, (unsigned)ix[0]), __builtin_bit_cast(float, (unsigned)ix[1])};
+    float invq[2];
+    if constexpr (PLO) {
+        const float l_tot = half_swap_sum(l_run);
+        const float inv = 1.0f / l_tot;
+        const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
+        invq[0] = __builtin_bit_cast(float, (unsigned)ix[0]); invq[1] = __builtin_bit_cast(float, (unsigned)ix[1]);
+    } else {                                                         // every row of the ones product holds the sum of query 16 qb + (lane & 15)
+        invq[0] = 1.0f / osum[0][0]; invq[1] = 1.0f / osum[1][0];
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qs2 = blockIdx.x * 256 + wave * 32 + 16 * qb + (lane & 15);
@@ -401,6 +423,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 // The P values leave the softmax in the 32x32 accumulator layout (lane = (query, half), 16 keys); one v_permlane16_swap per
 // register pair turns them into the two B operands of the 16-wide shape (queries 0-15 / 16-31 of the wave, four key groups of
 // eight), V^T is stored in the matching key order by transpose_v_kernel.
+template <bool PLO, bool QLO>
 __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
                                                               const half_t* __restrict__ vt_lo) {
     constexpr int L = 64, HD = 80, KS = 5, NDB = 5, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, NPAIR = NTILE / 2;
@@ -541,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
     for (int n = 0; n < NDB; ++n)
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) o[n][qb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    floatx4 osum[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};   // !PLO: row sums of the ROUNDED probabilities (see ones8)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 xh[2][2] = {}, xl[2][2] = {};                              // P^T as B operands of the 16x16x32 shape: [tile of the pair][query block]
     // V^T fragment of this lane: row (lane & 15) of a 16-row block, key group lane >> 4; position swizzled like the DMA image
@@ -559,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                 const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[e], 0, 0, 0);
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[e], 0, 0, 0);
-                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[e], 0, 0, 0);
+                if constexpr (QLO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[e], 0, 0, 0);
             }
         }
     };
@@ -598,9 +622,10 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     const half8 bh = __builtin_bit_cast(half8, xh[e][qb]), bl = __builtin_bit_cast(half8, xl[e][qb]);
+                    if constexpr (!PLO && db == 0) osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8(), bh, osum[qb], 0, 0, 0);
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[db][qb], 0, 0, 0);
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[db][qb], 0, 0, 0);
-                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[db][qb], 0, 0, 0);
+                    if constexpr (PLO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[db][qb], 0, 0, 0);
                 }
             } else {
                 constexpr int e = (I - NPV) / 5, ks = (I - NPV) % 5;
@@ -610,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                 }
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s[e], 0, 0, 0);
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s[e], 0, 0, 0);
-                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s[e], 0, 0, 0);
+                if constexpr (QLO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s[e], 0, 0, 0);
             }
         };
         load(std::integral_constant<int, 0>{});
@@ -679,6 +704,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
             const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
 #pragma unroll
             for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
+            osum[0] *= a0; osum[1] *= a1;
         }
         m_run = m_new;
         // P (hi, lo): the first eight values of a tile (keys {0-3, 8-11} + 4 half) and the last eight ({16-19, 24-27} + 4 half)
@@ -690,14 +716,20 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const f32x2 v0 = z[e][p], v1 = z[e][4 + p];
-                const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
-                const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
-                const unsigned l0 = split_lo_pk(h0, v0.x, v0.y);
-                const unsigned l1 = split_lo_pk(h1, v1.x, v1.y);
+                unsigned h0, h1;
+                if constexpr (PLO) {
+                    h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0.x, v0.y));
+                    h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v1.x, v1.y));
+                    const unsigned l0 = split_lo_pk(h0, v0.x, v0.y);
+                    const unsigned l1 = split_lo_pk(h1, v1.x, v1.y);
+                    const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+                    xl[e][0][p] = (unsigned)rl[0]; xl[e][1][p] = (unsigned)rl[1];
+                } else {                                             // one fp16 per probability, rounded to nearest
+                    h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, half2v));
+                    h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, half2v));
+                }
                 const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
-                const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
                 xh[e][0][p] = (unsigned)rh[0]; xh[e][1][p] = (unsigned)rh[1];
-                xl[e][0][p] = (unsigned)rl[0]; xl[e][1][p] = (unsigned)rl[1];
             }
     };
 
@@ -734,10 +766,15 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
     }
     if (!grpB) phase_barrier();                                      // match B's extra leading barrier
 
-    const float l_tot = half_swap_sum(l_run);
-    const float inv = 1.0f / l_tot;
-    const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
-    const float invq[2] = {__builtin_bit_cast(float, (unsigned)ix[0]), __builtin_bit_cast(float, (unsigned)ix[1])};
+    float invq[2];
+    if constexpr (PLO) {
+        const float l_tot = half_swap_sum(l_run);
+        const float inv = 1.0f / l_tot;
+        const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
+        invq[0] = __builtin_bit_cast(float, (unsigned)ix[0]); invq[1] = __builtin_bit_cast(float, (unsigned)ix[1]);
+    } else {                                                         // every row of the ones product holds the sum of query 16 qb + (lane & 15)
+        invq[0] = 1.0f / osum[0][0]; invq[1] = 1.0f / osum[1][0];
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int qs2 = blockIdx.x * 256 + wave * 32 + 16 * qb + (lane & 15);
@@ -801,7 +838,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g
 
 // ---- V^T workspace: caller-owned (cvlm_attn_args.workspace, size from cvlm_attention_workspace_bytes())
 int64_t cvlm_attention_global64_pp_workspace_bytes(const cvlm_attn_args& g) {
-    if (g.mode != 1 || g.hd != 80 || g.split_qk != 3 || g.split_pv != 3 || (g.grid != 64 && g.grid != 96)) return 0;
+    if (g.mode != 1 || g.hd != 80 || g.split_qk != g.split_pv || (g.split_qk != 3 && g.split_qk != 2) || (g.grid != 64 && g.grid != 96)) return 0;
     return (int64_t)2 * g.B * g.heads * 80 * g.grid * g.grid * (int64_t)sizeof(half_t);
 }
 
@@ -810,8 +847,8 @@ extern "C" int cvlm_debug_set_attn_g64_trace(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_g64_trace), &buf, sizeof(buf));
 }
 
-// exact-mode (split 3/3) fast path of cvlm_attention_global64()
-template <int L>
+// split 3/3 (PLO = QLO = true) or 2/2 form of cvlm_attention_global64()
+template <int L, bool PLO, bool QLO>
 static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int S = L * L;
     constexpr int smem = 3 * (2 * 5632) + (L == 64 ? 3 : 2) * (2 * 6144) + 256 * (L + 1) * 4;
@@ -824,23 +861,25 @@ static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
         constexpr int smem2 = 4 * (2 * 5632) + 4 * (2 * 6144) + 256 * (L + 1) * 4;
         static bool attr2[16] = {};
         if (cvlm_first_on_device(attr2))
-            (void)hipFuncSetAttribute((const void*)attn_g64pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
-        hipLaunchKernelGGL(attn_g64pair_kernel, dim3(S / 256, g.heads, g.B), dim3(512), smem2, s, g, (const half_t*)vt,
+            (void)hipFuncSetAttribute((const void*)attn_g64pair_kernel<PLO, QLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+        hipLaunchKernelGGL((attn_g64pair_kernel<PLO, QLO>), dim3(S / 256, g.heads, g.B), dim3(512), smem2, s, g, (const half_t*)vt,
                            (const half_t*)(vt + plane));
     } else {                                                          // 96 x 96 map: one 32-key tile per phase
         static bool attr[16] = {};
         if (cvlm_first_on_device(attr))
-            (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipLaunchKernelGGL(attn_g64pp_kernel<L>, dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
+            (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L, PLO, QLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipLaunchKernelGGL((attn_g64pp_kernel<L, PLO, QLO>), dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
                            (const half_t*)(vt + plane));
     }
     CVLM_CHECK_LAUNCH();
     return 0;
 }
 
-// exact-mode (split 3/3) global attention on a 64x64 or 96x96 token map
+// global attention on a 64x64 or 96x96 token map: split 3/3 (hi/lo operands on both sides of both products) or 2/2
 int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s) {
-    if (g.grid == 64) return launch_pp<64>(g, s);
-    if (g.grid == 96) return launch_pp<96>(g, s);
+    const bool full = g.split_qk == 3 && g.split_pv == 3;
+    if (!full && !(g.split_qk == 2 && g.split_pv == 2)) return CVLM_E_UNSUPPORTED;
+    if (g.grid == 64) return full ? launch_pp<64, true, true>(g, s) : launch_pp<64, false, false>(g, s);
+    if (g.grid == 96) return full ? launch_pp<96, true, true>(g, s) : launch_pp<96, false, false>(g, s);
     return CVLM_E_UNSUPPORTED;
 }

@@ -76,6 +76,8 @@ __device__ unsigned long long* g_win2_trace = nullptr;
 #define WIN2_STAMP(x) do { } while (0)
 #endif
 
+// PLO / QLO: as in attention_g64pp.hip (split 3: true; split 2: one fp16 per probability, Q's hi plane)
+template <bool PLO, bool QLO>
 __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_args g, const int nwx, const int npairs) {
     constexpr int HD = 80, KS = 5, NDB = 5, CPR = 10, KP = 80, VP = 80, L = 14, S_SEQ = 196;
     constexpr int KT = 32, NKT = 7, NCW = 7;                        // 7 key tiles, 7 consumer waves
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
         for (int n = 0; n < NDB; ++n)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) o[n][qb] = floatx4{0.f, 0.f, 0.f, 0.f};
+        floatx4 osum[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};   // !PLO: sums of the rounded probabilities (ones . P^T, as in attention_g64pp.hip)
 
         // S^T tile of key tile t of this pair (stream tile gt0 + t): 15 + 4 (bias) MFMAs
         auto scores = [&](int t, auto last_c) -> floatx16 {
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                 const half8 kl = *(const half8*)(kr + PLANE_B / 2 + 16 * ks);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+                if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
             }
             const int row = t * KT + qc;
             const half_t* ohr = OH + row * 32;
@@ -407,6 +410,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                 const float a0 = __builtin_bit_cast(float, (unsigned)ax[0]), a1 = __builtin_bit_cast(float, (unsigned)ax[1]);
 #pragma unroll
                 for (int n = 0; n < NDB; ++n) { o[n][0] *= a0; o[n][1] *= a1; }
+                osum[0] *= a0; osum[1] *= a1;
                 m_run = m_new;
             }
             const f32x2 c2 = f32x2{-m_run * LOG2E, -m_run * LOG2E}, l2 = f32x2{LOG2E, LOG2E};
@@ -425,15 +429,21 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 #pragma unroll
             for (int p2 = 0; p2 < 4; ++p2) {
                 const f32x2 e0 = z[p2], e1 = z[4 + p2];
-                const unsigned h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0.x, e0.y));
-                const unsigned h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e1.x, e1.y));
-                const half2v f0 = __builtin_bit_cast(half2v, h0), f1 = __builtin_bit_cast(half2v, h1);
-                const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0.x - (float)f0[0], e0.y - (float)f0[1]));
-                const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e1.x - (float)f1[0], e1.y - (float)f1[1]));
+                unsigned h0, h1;
+                if constexpr (PLO) {
+                    h0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0.x, e0.y));
+                    h1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e1.x, e1.y));
+                    const half2v f0 = __builtin_bit_cast(half2v, h0), f1 = __builtin_bit_cast(half2v, h1);
+                    const unsigned l0 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e0.x - (float)f0[0], e0.y - (float)f0[1]));
+                    const unsigned l1 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(e1.x - (float)f1[0], e1.y - (float)f1[1]));
+                    const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
+                    xl[0][p2] = (unsigned)rl[0]; xl[1][p2] = (unsigned)rl[1];
+                } else {                                             // one fp16 per probability, rounded to nearest; denominator: osum
+                    h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(e0, half2v));
+                    h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(e1, half2v));
+                }
                 const auto rh = __builtin_amdgcn_permlane16_swap(h0, h1, false, false);
-                const auto rl = __builtin_amdgcn_permlane16_swap(l0, l1, false, false);
                 xh[0][p2] = (unsigned)rh[0]; xh[1][p2] = (unsigned)rh[1];
-                xl[0][p2] = (unsigned)rl[0]; xl[1][p2] = (unsigned)rl[1];
             }
             auto pv = [&](int db, half4 (&v0)[2], half4 (&v1)[2]) {
                 const half8 vh = half8{v0[0][0], v0[0][1], v0[0][2], v0[0][3], v1[0][0], v1[0][1], v1[0][2], v1[0][3]};
@@ -441,9 +451,13 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     const half8 bh = __builtin_bit_cast(half8, xh[qb]), bl = __builtin_bit_cast(half8, xl[qb]);
+                    if (!PLO && db == 0) {
+                        const half_t one = (half_t)1.0f;
+                        osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(half8{one, one, one, one, one, one, one, one}, bh, osum[qb], 0, 0, 0);
+                    }
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bh, o[db][qb], 0, 0, 0);
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, bh, o[db][qb], 0, 0, 0);
-                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bl, o[db][qb], 0, 0, 0);
+                    if constexpr (PLO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bl, o[db][qb], 0, 0, 0);
                 }
             };
             lds_wait();                                               // blocks 0..2 (and everything older) are in registers
@@ -467,10 +481,15 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
         // ---- output.  A lane holds dims 16 db + 4 g .. + 3 of queries (lane & 15) + 16 qb; one v_permlane16_swap per register
         // pair hands a neighbouring 4-dim piece across (even g: the next four dims of block db from lane + 16; odd g: the four
         // dims below of block db + 1 from lane - 16), so blocks (0, 1) and (2, 3) leave in 16-byte stores, block 4 in 8-byte ones
-        const float l_tot = half_swap_sum(l_run);
-        const float inv = 1.0f / l_tot;
-        const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
-        const float invq[2] = {__builtin_bit_cast(float, (unsigned)ix[0]), __builtin_bit_cast(float, (unsigned)ix[1])};
+        float invq[2];
+        if constexpr (PLO) {
+            const float l_tot = half_swap_sum(l_run);
+            const float inv = 1.0f / l_tot;
+            const auto ix = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, inv), __builtin_bit_cast(unsigned, inv), false, false);
+            invq[0] = __builtin_bit_cast(float, (unsigned)ix[0]); invq[1] = __builtin_bit_cast(float, (unsigned)ix[1]);
+        } else {                                                      // every row of the ones product holds the sum of query 16 qb + (lane & 15)
+            invq[0] = 1.0f / osum[0][0]; invq[1] = 1.0f / osum[1][0];
+        }
         const int g4 = lane >> 4;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -525,21 +544,28 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 extern "C" int cvlm_debug_set_attn_win2_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_win2_trace), &buf, sizeof(buf)); }
 #endif
 
-// exact-mode (split 3/3) producer / consumer form; called from cvlm_attention_window14() when selected
-int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s) {
+// split 3/3 or 2/2, producer / consumer form; called from cvlm_attention() for the SAM window geometry
+template <bool PLO, bool QLO>
+static int launch_win14(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int smem = 6 * 10240 + 17 * 1024 + 224 * 32 * 2 + 2 * (2 * 224 * 8) + 224 * 17 * 4;
     const int nwx = (g.grid + 13) / 14;
     const int npairs = g.heads * g.B * nwx * nwx;
     static bool attr[16] = {};
     if (cvlm_first_on_device(attr))
-        (void)hipFuncSetAttribute((const void*)attn_win14p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_win14p_kernel<PLO, QLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     static int cus_[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     int& cus = cus_[dev & 15];
     if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const int wgs = npairs < cus ? npairs : cus;
-    hipLaunchKernelGGL(attn_win14p_kernel, dim3(wgs), dim3(512), smem, s, g, nwx, npairs);
+    hipLaunchKernelGGL((attn_win14p_kernel<PLO, QLO>), dim3(wgs), dim3(512), smem, s, g, nwx, npairs);
     CVLM_CHECK_LAUNCH();
     return 0;
+}
+
+int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s) {
+    if (g.split_qk == 3 && g.split_pv == 3) return launch_win14<true, true>(g, s);
+    if (g.split_qk == 2 && g.split_pv == 2) return launch_win14<false, false>(g, s);
+    return CVLM_E_UNSUPPORTED;
 }

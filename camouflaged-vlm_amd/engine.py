@@ -26,8 +26,11 @@ from .spec import ClipGeometry, SamGeometry
 @dataclass(frozen=True)
 class Precision:
     """split = 3: hi*hi + lo*hi + hi*lo products (fp32-grade, the parity mode); 1: fp16 operands.
-    mx: the GEMMs whose operands only GEMMs touch (qkv / lin1 / lin2 of the ViT-H blocks) form the two correction products lo*hi and
-    hi*lo on the block-scaled e4m3 matrix instruction (include/cvlm.h ABI 10); everything else is split = 3."""
+    mx: the GEMMs whose operands only GEMMs touch (qkv / lin1 / lin2 of the ViT-H blocks, the CLIP MLPs) form the two correction products
+    lo*hi and hi*lo on the block-scaled e4m3 matrix instruction (include/cvlm.h ABI 10); the other GEMMs are split = 3.
+    qk / pv = 2 (ABI 11, the ViT-H attention kernels): the products keep the lo planes of K and V and drop those of Q and of the
+    probabilities (one fp16 per probability, the softmax denominator summed from the rounded values): two MFMAs per product instead of three.
+    `mx` = both economies, on batches of two or more images; one image per call runs the `exact` arithmetic (SamEncoder.attn_split)."""
     gemm: int = 3
     qk: int = 3
     pv: int = 3
@@ -35,7 +38,8 @@ class Precision:
 
     @staticmethod
     def named(name: str) -> "Precision":
-        return {"exact": Precision(3, 3, 3), "mx": Precision(3, 3, 3, True), "fast": Precision(1, 1, 1), "mixed": Precision(3, 3, 1)}[name]
+        return {"exact": Precision(3, 3, 3), "mx": Precision(3, 2, 2, True), "mx33": Precision(3, 3, 3, True), "fast": Precision(1, 1, 1),
+                "mixed": Precision(3, 3, 1)}[name]
 
 
 # Static power-of-two scales that keep UNBOUNDED activations inside fp16 range when they become h2 GEMM operands
@@ -373,6 +377,7 @@ class SamEncoder(_Base):
         hid = ws.h2("hid", M, HK)
         hid_prm = H2(hid.t[:, :, g.mlp_dim:])                      # the PK trailing columns (same row pitch)
         fold = taps is None                                        # block taps need x before the next prompt is added
+        sq, sp = self.attn_split(M)
         if fold and self.ln_fold and not self.fold_disabled:
             return self._blocks_folded(x, feat, prm, qkv, att, hid, hid_prm, B)
         for i, blk in enumerate(self.blocks):
@@ -387,11 +392,11 @@ class SamEncoder(_Base):
             self.gemm(xn, blk["qkv"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim))
             if blk["window"] > 0:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
-                               pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
+                               pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=sq, split_pv=sp,
                                head_major=True, scale=1.0)
             else:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
-                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True, scale=1.0)
+                               rel_w=blk["rel_w"], split_qk=sq, split_pv=sp, head_major=True, scale=1.0)
             self.gemm(att, blk["proj"], M, residual=x, out_f32=x)
             hip.layernorm(x, blk["n2w"], blk["n2b"], 1e-6, M, D, out_h2=xn)
             self.gemm(xn, blk["lin1"], M, out_h2=hid, ldoh=HK, act=ACT_GELU, out_scale=HID_SCALE)
@@ -405,6 +410,12 @@ class SamEncoder(_Base):
             self._hook(i)
         hip.add_rows(x, None, 1, M, D, scale=X_SCALE, out_h2=xn)
         return self._neck(xn, B)
+
+    def attn_split(self, M: int):
+        """Terms of the attention products for a forward over M token rows: precision `mx` spends its error budget where it buys time --
+        batches; one image per call (M <= 4096) keeps three terms, like its GEMMs keep split-3 operands (_blocks_folded)."""
+        pr = self.prec
+        return (3, 3) if (pr.mx and M <= 4096) else (pr.qk, pr.pv)
 
     def _blocks_folded(self, x, feat, prm, qkv, att, hid, hid_prm, B: int) -> torch.Tensor:
         """The 32 blocks without LayerNorm passes.  The residual stream lives in h2 (xh = x * X_SCALE); proj and lin2
@@ -454,17 +465,18 @@ class SamEncoder(_Base):
             hid = ws.h2mx("hid_mx", M, HK)
             hid_prm = hid.cols(g.mlp_dim)
         hk = {} if use_il else {"ldoh": HK}                          # the image carries its own row stride
+        sq, sp = self.attn_split(M)
         for i, blk in enumerate(self.blocks):
             hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)
             self.gemm(xh, blk["qkv_f"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim), alpha=inv,
                       ln_fold=(mrg, blk["qkv_f"].colsum))
             if blk["window"] > 0:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
-                               pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv,
+                               pad=blk["pad"], rel_h=blk["rel_h"], rel_w=blk["rel_w"], split_qk=sq, split_pv=sp,
                                head_major=True, scale=1.0)
             else:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=1, grid=G, rel_h=blk["rel_h"],
-                               rel_w=blk["rel_w"], split_qk=pr.qk, split_pv=pr.pv, head_major=True, scale=1.0)
+                               rel_w=blk["rel_w"], split_qk=sq, split_pv=sp, head_major=True, scale=1.0)
             self.gemm(att, blk["proj"], M, out_h2=xo, residual_h2=(xh, inv), out_scale=X_SCALE, row_stats=pcs)
             xh = xo                                                  # from here on the stream is read where it was written
             hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)

@@ -26,7 +26,7 @@ EXPORTS = [
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_row_stats_split_mx", "cvlm_gather_rows_h2",
     "cvlm_ln_stats_merge", "cvlm_small_attention_h2", "cvlm_prob_quantise", "cvlm_prob_moments", "cvlm_prob_wfm",
 ]
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class GemmArgs(C.Structure):

@@ -67,7 +67,7 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap = argparse.ArgumentParser(prog="python -m camouflaged_vlm_amd.run", description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--device", type=int, default=None, help="GPU index to run on (see above)")
-    ap.add_argument("--precision", choices=["exact", "mx", "mixed", "fast"], default=None,
+    ap.add_argument("--precision", choices=["exact", "mx", "mx33", "mixed", "fast"], default=None,
                     help="sets CVLM_PRECISION for the drop-in modules (default exact: the parity mode)")
     ap.add_argument("script", help="the reference script to run, e.g. demo.py")
     ap.add_argument("args", nargs=argparse.REMAINDER, help="arguments of the script")

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 10
+#define CVLM_ABI_VERSION 11
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -217,7 +217,14 @@ int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, 
  *         q = k = v = qkv bias (pad_hi/pad_lo = h2 of the 3*heads*hd bias vector).
  * rel_h/rel_w: h2 [(2*L-1)][hd] tables (L = grid or window).  scale = hd^-0.5 applied to q.k only.
  * out: h2 [B*S_img][heads*hd].
- * workspace: the exact-mode (split 3/3) global kernels for the 64x64 and 96x96 maps keep V transposed
+ * split_qk / split_pv: fp16 MFMA products per multiply of q.k^T / P.v.  3: hi/lo operands on both sides (hi.hi + lo.hi + hi.lo, fp32-grade);
+ *   1: hi planes only (lo pointers may be NULL); (3, 1) mixes them.  ABI 11 -- (2, 2): K and V keep their lo planes, Q and the
+ *   probabilities P do not: q.k^T = q_hi.(k_hi + k_lo), P.v = fp16(P).(v_hi + v_lo) with P rounded to nearest and the softmax denominator
+ *   summed from the rounded values (a ones-row product), so the quotient is an exact weighted mean of V rows with weights off by
+ *   <= 2^-12 relative.  (Dropping the lo plane of K or V instead is NOT fp32-grade: profiles/r05_precision_sensitivity.log.)  The two
+ *   ViT-H kernels (mode 1 on 64x64 / 96x96 maps, mode 2 with 14x14 windows) have this form; every other shape runs (2, 2) as (3, 3).
+ *   All lo pointers are required, as for 3.
+ * workspace: the split 3/3 and 2/2 global kernels for the 64x64 and 96x96 maps keep V transposed
  * (cvlm_attention_workspace_bytes(args) bytes, 0 for every other mode); CVLM_E_WORKSPACE if it is missing there. */
 typedef struct cvlm_attn_args {
     const void* qkv_hi; const void* qkv_lo;

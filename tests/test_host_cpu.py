@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/cvlm.h but not exported"
     assert set(hip.EXPORTS) == declared
-    assert lib.cvlm_abi_version() == hip.ABI_VERSION == 10 and lib.cvlm_target_arch() == b"gfx950"
+    assert lib.cvlm_abi_version() == hip.ABI_VERSION == 11 and lib.cvlm_target_arch() == b"gfx950"
 
 
 def test_integration_doc_struct_matches_binding():
