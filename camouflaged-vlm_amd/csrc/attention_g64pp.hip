@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             const half8 kh = *(const half8*)(kr + 16 * ks);
             const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+            if constexpr (CVLM_ATTN_K_LO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
             if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
         }
     };
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
                     const half8 bh = __builtin_bit_cast(half8, xh[qb]), bl = __builtin_bit_cast(half8, xl[qb]);
                     if constexpr (!PLO && I == 0) osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8(), bh, osum[qb], 0, 0, 0);
                     o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[I][qb], 0, 0, 0);
-                    o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[I][qb], 0, 0, 0);
+                    if constexpr (CVLM_ATTN_V_LO) o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[I][qb], 0, 0, 0);
                     if constexpr (PLO) o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[I][qb], 0, 0, 0);
                 }
             } else {
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
                     for (int r = 0; r < 16; ++r) s[r] = 0.f;
                 }
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s, 0, 0, 0);
+                if constexpr (CVLM_ATTN_K_LO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s, 0, 0, 0);
                 if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s, 0, 0, 0);
             }
         };
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                 const half8 kh = *(const half8*)(kr + 16 * ks);
                 const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[e], 0, 0, 0);
-                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[e], 0, 0, 0);
+                if constexpr (CVLM_ATTN_K_LO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[e], 0, 0, 0);
                 if constexpr (QLO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[e], 0, 0, 0);
             }
         }
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                     const half8 bh = __builtin_bit_cast(half8, xh[e][qb]), bl = __builtin_bit_cast(half8, xl[e][qb]);
                     if constexpr (!PLO && db == 0) osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8(), bh, osum[qb], 0, 0, 0);
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[db][qb], 0, 0, 0);
-                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[db][qb], 0, 0, 0);
+                    if constexpr (CVLM_ATTN_V_LO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[db][qb], 0, 0, 0);
                     if constexpr (PLO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[db][qb], 0, 0, 0);
                 }
             } else {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                     for (int r = 0; r < 16; ++r) s[e][r] = 0.f;
                 }
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s[e], 0, 0, 0);
-                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s[e], 0, 0, 0);
+                if constexpr (CVLM_ATTN_K_LO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s[e], 0, 0, 0);
                 if constexpr (QLO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s[e], 0, 0, 0);
             }
         };
@@ -879,6 +879,10 @@ static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
 int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s) {
     const bool full = g.split_qk == 3 && g.split_pv == 3;
     if (!full && !(g.split_qk == 2 && g.split_pv == 2)) return CVLM_E_UNSUPPORTED;
+    if constexpr (CVLM_ATTN_TERMS >= 0) {                            // probe builds: the build names the terms
+        constexpr bool P = (CVLM_ATTN_TERMS & 1) != 0, Q = (CVLM_ATTN_TERMS & 2) != 0;
+        return g.grid == 64 ? launch_pp<64, P, Q>(g, s) : g.grid == 96 ? launch_pp<96, P, Q>(g, s) : CVLM_E_UNSUPPORTED;
+    }
     if (g.grid == 64) return full ? launch_pp<64, true, true>(g, s) : launch_pp<64, false, false>(g, s);
     if (g.grid == 96) return full ? launch_pp<96, true, true>(g, s) : launch_pp<96, false, false>(g, s);
     return CVLM_E_UNSUPPORTED;

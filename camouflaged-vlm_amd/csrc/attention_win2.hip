@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                 const half8 kh = *(const half8*)(kr + 16 * ks);
                 const half8 kl = *(const half8*)(kr + PLANE_B / 2 + 16 * ks);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                if constexpr (CVLM_ATTN_K_LO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
                 if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
             }
             const int row = t * KT + qc;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                         osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(half8{one, one, one, one, one, one, one, one}, bh, osum[qb], 0, 0, 0);
                     }
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bh, o[db][qb], 0, 0, 0);
-                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, bh, o[db][qb], 0, 0, 0);
+                    if constexpr (CVLM_ATTN_V_LO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, bh, o[db][qb], 0, 0, 0);
                     if constexpr (PLO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bl, o[db][qb], 0, 0, 0);
                 }
             };
@@ -565,6 +565,7 @@ static int launch_win14(const cvlm_attn_args& g, hipStream_t s) {
 }
 
 int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s) {
+    if constexpr (CVLM_ATTN_TERMS >= 0) return launch_win14<(CVLM_ATTN_TERMS & 1) != 0, (CVLM_ATTN_TERMS & 2) != 0>(g, s);   // probe builds (common.h)
     if (g.split_qk == 3 && g.split_pv == 3) return launch_win14<true, true>(g, s);
     if (g.split_qk == 2 && g.split_pv == 2) return launch_win14<false, false>(g, s);
     return CVLM_E_UNSUPPORTED;

@@ -2,8 +2,8 @@
 # One attention operand's lo plane dropped at a time on top of the split-3 engine (--precision exact): the "alone" column of the table
 cd "$(dirname "$0")/.."
 OUT=${OUT:-gpurun_out/attn_terms}; mkdir -p $OUT
-for n in ${NAMES:-base p q pq}; do
-    if [ $n = base ]; then unset CVLM_PROBE_LIB; else export CVLM_PROBE_LIB=$PWD/camouflaged-vlm_amd/lib_terms/$n/libcvlm_hip.so; fi
+for n in ${NAMES:-none p q pq}; do
+    export CVLM_PROBE_LIB=$PWD/camouflaged-vlm_amd/lib_terms/$n/libcvlm_hip.so
     python bench.py --precision exact --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_exact_$n.json 2>$OUT/bench_exact_$n.err
     python - $OUT/bench_exact_$n.json $n <<'PY' | tee -a $OUT/summary_alone.log
 import json, sys
