@@ -18,8 +18,8 @@ ws = H.new_gemm_workspace(dev)
 REPS, INNER = int(os.environ.get("REPS", "3")), int(os.environ.get("INNER", "10"))
 for name, M, N, K, form in shapes:
     torch.manual_seed(0)
-    ap = H.H2(torch.stack([(torch.randn(M, K) * 0.25).half(), (torch.randn(M, K) * 1e-4).half()]))
-    wp = H.H2(torch.stack([(torch.randn(N, K) * 0.5).half(), (torch.randn(N, K) * 2e-4).half()]))
+    ap, wp = H.H2.pack(torch.randn(M, K) * 0.25), H.H2.pack(torch.randn(N, K) * 0.5)      # real split planes: an mx image of planes whose lo is not the
+    #                                                                                        rounding residual of hi overflows e4m3 (NaN bytes)
     A_il, A_mx = H.H2IL.from_planes(H.H2(ap.t.to(dev))), H.H2MX.from_planes(ap)
     A_mx = H.H2MX(A_mx.t.to(dev), A_mx.s.to(dev), None, A_mx.C)
     W = H.H2(wp.t.to(dev))
@@ -38,10 +38,10 @@ for name, M, N, K, form in shapes:
         kw.update(act=H.ACT_GELU, out_scale=0.25)
         outs = {"split3": H.H2IL.empty(M, N, device=dev), "mx": H.H2MX.empty(M, N, device=dev)}
     else:
-        r_il = H.H2IL.from_planes(H.H2(torch.randn(2, M, N, device=dev).half()))
+        r_il = H.H2IL.from_planes(H.H2(H.H2.pack(torch.randn(M, N)).t.to(dev)))
         r_mx = H.H2MX.empty(M, N, device=dev, lo_plane=True)
-        r_mx.t.copy_(H.H2MX.from_planes(H.H2(torch.randn(2, M, N).half())).t)
-        r_mx.lo.normal_()
+        r_mx.t.copy_(H.H2MX.from_planes(H.H2.pack(torch.randn(M, N))).t)
+        r_mx.lo.normal_(std=1e-4)
         stats = torch.zeros(H.stats_pieces(N), M, 2, device=dev)
         kw.update(row_stats=stats)
         outs = {"split3": r_il, "mx": r_mx}
