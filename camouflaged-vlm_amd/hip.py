@@ -170,7 +170,9 @@ def mx_scale_pitch(C_: int) -> int:
 def mx_pack(x: "H2"):
     """h2 planes [2][R][C] (C % 64 == 0) -> (image uint8 [R][C / 64][256], scales uint8 [R][4][mx_scale_pitch(C)]) of include/cvlm.h
     ABI 10, in torch (weights at load time; the reference the tests hold the GEMM epilogue's own mx output against, bit for bit):
-    per 32 columns E = max(exponent field of the largest |hi| as f32, 103) - 7, hi8 = e4m3(hi / 2^(E - 127)), lo8 = e4m3(lo / 2^(E - 138))."""
+    per 32 columns E = max(exponent field of the largest |hi| as f32, 103) - 7, hi8 = e4m3(hi / 2^(E - 127)), lo8 = e4m3(lo / 2^(E - 138)).
+    `lo` must be what the split leaves (|lo| <= half an ulp of its hi: H2.pack, every producer kernel): the lo8 scale is sized for that, and a
+    plane of unrelated values overflows e4m3 (NaN bytes, as the hardware conversion gives)."""
     two, R, C_ = x.t.shape
     assert two == 2 and C_ % 64 == 0
     hi, lo = x.t[0], x.t[1]
