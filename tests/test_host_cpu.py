@@ -510,3 +510,25 @@ def test_every_rank_draws_its_batches_from_the_reference_digest():
           "mask_samples": np.zeros((2, 1), np.float32), "class_logits": np.zeros((2, 3), np.float32)}
     r = digest.check_cascade(FakeT(np.zeros((1, 1, 2, 2), np.float32)), FakeT(np.zeros(1, np.int64)), FakeT(np.zeros((1, 3), np.float32)), dg, [5])
     assert r == {"checked_images": [], "ok": None}
+
+
+def test_precision_modes_and_what_one_image_per_call_runs():
+    """engine.Precision: `mx` = mx GEMM operands + two-term attention products (include/cvlm.h ABI 10 / 11), on batches; one image per call
+    (M <= 4096 token rows of the 64 x 64 map) keeps the three-term products of `exact`, like its GEMMs keep split-3 operands."""
+    import types
+    from camouflaged_vlm_amd.engine import Precision, SamEncoder
+    from camouflaged_vlm_amd import host
+    assert Precision.named("exact") == Precision(3, 3, 3, False)
+    assert Precision.named("mx") == Precision(3, 2, 2, True) and Precision.named("mx33") == Precision(3, 3, 3, True)
+    old = os.environ.pop("CVLM_PRECISION", None)
+    try:
+        assert host.precision_from_env() == Precision.named("mx")
+        os.environ["CVLM_PRECISION"] = "exact"
+        assert host.precision_from_env() == Precision.named("exact")
+    finally:
+        os.environ.pop("CVLM_PRECISION", None)
+        if old is not None:
+            os.environ["CVLM_PRECISION"] = old
+    split = lambda name, M: SamEncoder.attn_split(types.SimpleNamespace(prec=Precision.named(name)), M)
+    assert split("mx", 4096) == (3, 3) and split("mx", 8192) == (2, 2) and split("mx", 32768) == (2, 2)
+    assert split("exact", 32768) == (3, 3) and split("mx33", 32768) == (3, 3) and split("fast", 4096) == (1, 1)
