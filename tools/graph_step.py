@@ -9,7 +9,7 @@ sys.path.insert(0, cv.DROPIN_DIR)
 from cocotrainers.mapleAlphaCLIP import gather_text_features
 g, c, B, dev = spec.DEMO_SAM, spec.DEMO_CLIP, int(os.environ.get("BATCH", "8")), torch.device("cuda", 0)
 sd = {k: torch.from_numpy(v) for k, v in synth.make_full_state_dict(g, c).items()}
-cas = Cascade(sd, g, c, dev, Precision.named("exact"))
+cas = Cascade(sd, g, c, dev, Precision.named(os.environ.get("PRECISION", "mx")))
 eot = host.eot_for_classes(host.ovcamo_constants()["names_test"].tolist())[:c.n_cls_test]
 bank = torch.from_numpy(host.ovcamo_constants()["bank_test"][:c.n_cls_test]).float()
 cas.clip.set_text_bank(gather_text_features(cas.clip, eot, "test"), bank, "test")

@@ -10,10 +10,12 @@ with open(f) as fh:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 short = lambda n: re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", ""))[:60]
-# middle third of the trace = steady-state steps (the head holds weight uploads, the tail the parity check and CPU work);
+# steady-state steps = from the middle to the 95th percentile of the GEMM launches (the head of a trace holds weight uploads and the
+# on-device weight packing -- thousands of torch kernels since round 5 --, the tail the parity check and CPU work);
 # "tail:<frac>" as second argument: the last <frac> of the kernels instead (short runs whose head is mostly uploads)
 n = len(rows)
-part = rows[n // 3: n * 2 // 3]
+gi = [i for i, r in enumerate(rows) if "gemm_nt_kernel" in r[2]]
+part = rows[gi[len(gi) // 2]: gi[len(gi) * 95 // 100]] if len(gi) >= 100 else rows[n // 3: n * 2 // 3]
 if len(sys.argv) > 2 and sys.argv[2].startswith("tail:"):
     part = rows[int(n * (1.0 - float(sys.argv[2][5:]))):]
     # per-kernel busy time, union over overlapping streams
