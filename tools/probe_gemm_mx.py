@@ -10,15 +10,14 @@ dev = "cuda"
 SHAPE = os.environ.get("SHAPE", "qkv")
 M, N, K = {"qkv": (32768, 3840, 1280), "lin1": (32768, 5120, 1280), "lin2": (32768, 1280, 5184)}[SHAPE]
 torch.manual_seed(0)
-ap = H.H2(torch.stack([(torch.randn(M, K) * 0.25).half(), (torch.randn(M, K) * 1e-4).half()]))
-wp = H.H2(torch.stack([(torch.randn(N, K) * 0.5).half(), (torch.randn(N, K) * 2e-4).half()]))
+ap, wp = H.H2.pack(torch.randn(M, K) * 0.25), H.H2.pack(torch.randn(N, K) * 0.5)       # real split planes (an mx image of unrelated planes holds NaN bytes)
 mv = lambda m: H.H2MX(m.t.to(dev), m.s.to(dev), None if m.lo is None else m.lo.to(dev), m.C)
 A_il, A_mx = H.H2IL.from_planes(H.H2(ap.t.to(dev))), mv(H.H2MX.from_planes(ap))
 W = H.H2(wp.t.to(dev)); W_il = H.interleave_planes(W); W_mx = mv(H.H2MX.from_planes(wp))
 kw = dict(bias=torch.randn(N, device=dev), workspace=H.new_gemm_workspace(dev), w_il=W_il)
 out_s3 = None
 if SHAPE == "lin2":                                                    # lin2: h2 residual + row statistics, mx out + lo plane, K-parts of the last half round
-    res = H.H2(torch.randn(2, M, N).half())
+    res = H.H2.pack(torch.randn(M, N))
     out = mv(H.H2MX.from_planes(res, lo_plane=True))
     out_s3 = H.H2IL.from_planes(H.H2(res.t.to(dev)))
     kw.update(row_stats=torch.zeros(H.stats_pieces(N), M, 2, device=dev))
