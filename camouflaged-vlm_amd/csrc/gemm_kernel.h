@@ -451,7 +451,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         constexpr int HALF_SLOT = 32768, NHS = 5;
         static_assert(BN == 256 && PER_WAVE * NWAVE == (BM + BN) / 8, "one staging instruction per 8 rows");
         constexpr int PW_A = BM / 8 / NWAVE, PW_W = BN / 8 / NWAVE;        // pieces per wave and unit: activation rows, weight rows
-        constexpr bool DMA_ONLY = DBG == 2 || (DBG >= 12 && DBG <= 15);
+        constexpr bool DMA_ONLY = DBG == 2 || (DBG >= 12 && DBG <= 18);
+        // probes 16-19 (tools/probe_gemm_mx.py): where do the operand stream's lines come from?  16 / 19: the activation rows of every tile wrapped
+        // into rows 0..255 (always L2-resident; 19: in the full kernel -- wrong numbers, right timing), 17: into rows 0..8191 (infinity-cache
+        // resident), 18: activation and weight rows both wrapped into 0..255
+        constexpr int WRAP_A = (DBG == 16 || DBG == 18 || DBG == 19) ? 255 : DBG == 17 ? 8191 : 0, WRAP_W = DBG == 18 ? 255 : 0;
         intx8 wf[4], af[MH];
         if (DBG == 9 || DMA_ONLY) {
 #pragma unroll
@@ -482,6 +486,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             int row = (isW ? bn : bm) + blk * 8;
             const int lim = (isW ? g.N : g.M) - 8;
             row = row < lim ? row : lim;
+            if (WRAP_A && !isW) row &= WRAP_A;
+            if (WRAP_W && isW) row &= WRAP_W;
             const char* base = (const char*)(isW ? Whi : Ahi) + (int64_t)row * (isW ? g.ldw_mx : g.lda) * 2 + k0_bytes + (int64_t)u * 128;   // a unit is 128 bytes of a row
             unsigned o = isW ? vw[blk & 1] : va[blk & 1];
             asm volatile("" : "+s"(base), "+v"(o));  // keep the address a scalar base + a 32-bit vector offset (left alone, the zero-extended offsets are hoisted as 64-bit pairs)

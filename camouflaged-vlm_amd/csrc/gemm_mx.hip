@@ -35,6 +35,10 @@ int cvlm_gemm_k::launch_mx(GemmParams& p, int mt, int epi, int extra_blocks, int
             case 13: return launch_one<8, 1, 13>(p, extra_blocks, s);
             case 14: return launch_one<8, 1, 14>(p, extra_blocks, s);
             case 15: return launch_one<8, 1, 15>(p, extra_blocks, s);
+            case 16: return launch_one<8, 1, 16>(p, extra_blocks, s);
+            case 17: return launch_one<8, 1, 17>(p, extra_blocks, s);
+            case 18: return launch_one<8, 1, 18>(p, extra_blocks, s);
+            case 19: return launch_one<8, 1, 19>(p, extra_blocks, s);
             default: break;
         }
     }
@@ -44,6 +48,10 @@ int cvlm_gemm_k::launch_mx(GemmParams& p, int mt, int epi, int extra_blocks, int
             case 2: return launch_one<8, 2, 2>(p, extra_blocks, s);
             case 3: return launch_one<8, 2, 3>(p, extra_blocks, s);
             case 6: return launch_one<8, 2, 6>(p, extra_blocks, s);
+            case 16: return launch_one<8, 2, 16>(p, extra_blocks, s);
+            case 17: return launch_one<8, 2, 17>(p, extra_blocks, s);
+            case 18: return launch_one<8, 2, 18>(p, extra_blocks, s);
+            case 19: return launch_one<8, 2, 19>(p, extra_blocks, s);
             default: break;
         }
     }

@@ -31,13 +31,17 @@ else:
         kw.update(head_major=(4096, 16, 80))
         out = H.H2.empty(M, N, device=dev)
 if SHAPE == "lin2":
-    PROBES = {"101", "102", "103", "106"}
+    PROBES = {"101", "102", "103", "106", "116", "117", "118", "119"}
 forms = [("split-3 kernel", None, "0"), ("mx kernel", 1, "0"), ("mx, no DMA in the steady state", 1, "101"), ("mx, DMA only (no reads, no MFMAs)", 1, "102"),
          ("mx, no fragment reads", 1, "109"), ("mx, only the f16 units multiply", 1, "110"), ("mx, only the fp8 units multiply", 1, "111"),
          ("mx, main loop only (no epilogue)", 1, "106"), ("mx, epilogue without its global stores", 1, "103"),
          ("mx, epilogue: LDS staging only (no split / conversion / stores)", 1, "105"),
          ("mx, epilogue stores aimed at 128 KB that stay in L2 (same instructions)", 1, "107"), ("mx, DMA only, sc0", 1, "112"), ("mx, DMA only, nt", 1, "113"), ("mx, DMA only, sc1", 1, "114"),
-         ("mx, DMA only, sc0 sc1", 1, "115")]
+         ("mx, DMA only, sc0 sc1", 1, "115"),
+         ("mx, DMA only, activation rows wrapped into rows 0..255 (L2-resident)", 1, "116"),
+         ("mx, DMA only, activation rows wrapped into rows 0..8191 (infinity-cache resident)", 1, "117"),
+         ("mx, DMA only, activation AND weight rows wrapped into rows 0..255", 1, "118"),
+         ("mx kernel, activation rows wrapped into rows 0..255 (timing only)", 1, "119")]
 if SHAPE == "lin2":
     forms = [f for f in forms if f[2] == "0" or f[2] in PROBES]
 res = {f[0]: [] for f in forms}
