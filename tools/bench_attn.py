@@ -30,3 +30,11 @@ Hc, hc, Sc = 16, 64, 581
 q2 = hip.H2(torch.randn(2, B * Sc, 3 * Hc * hc, device="cuda").half())
 o2 = hip.H2.empty(B * Sc, Hc * hc)
 run("clip vision", lambda: hip.attention(q2, o2, B, Sc, Hc, hc, mode=0, split_qk=split[0], split_pv=split[1]), 4.0 * B * Hc * Sc * Sc * hc)
+if os.environ.get("HIRES", "1") == "1":                                  # 1536^2 ViT-H (BASELINE configs[4]): 96 x 96 map, B = 4
+    B2, G2 = 4, 96
+    S2 = G2 * G2
+    qkv2 = hip.H2(torch.randn(2, B2 * S2, 3 * D, device="cuda").half())
+    out2 = hip.H2.empty(B2 * S2, D)
+    rg2 = hip.H2((torch.randn(2, 2 * G2 - 1, hd, device="cuda") * 0.1).half())
+    run("sam global 96", lambda: hip.attention(qkv2, out2, B2, S2, H, hd, mode=1, grid=G2, rel_h=rg2, rel_w=rg2, split_qk=split[0], split_pv=split[1], head_major=hm),
+        4.0 * B2 * H * S2 * S2 * hd)
