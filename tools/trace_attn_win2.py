@@ -9,12 +9,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from camouflaged_vlm_amd import hip
 lib = hip.load()
 B, H, hd, G = 8, 16, 80, 64
+SPLIT = int(os.environ.get("SPLIT", "2"))
 D, S = H * hd, G * G
 qkv = hip.H2(torch.randn(2, B * S, 3 * D, device="cuda").half())
 out = hip.H2.empty(B * S, D)
 rw = hip.H2((torch.randn(2, 27, hd, device="cuda") * 0.1).half())
 pad = hip.H2((torch.randn(2, 3 * D, device="cuda") * 0.1).half())
-fn = lambda: hip.attention(qkv, out, B, S, H, hd, mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw, split_qk=3, split_pv=3, head_major=True, scale=1.0)
+fn = lambda: hip.attention(qkv, out, B, S, H, hd, mode=2, grid=G, window=14, pad=pad, rel_h=rw, rel_w=rw, split_qk=SPLIT, split_pv=SPLIT, head_major=True, scale=1.0)
 nwg = torch.cuda.get_device_properties(0).multi_processor_count
 buf = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device="cuda")
 for _ in range(3): fn()
