@@ -43,8 +43,9 @@ def gather_text_features(engine: ClipModel, eot: Sequence[int], split: str) -> t
     same (n, 768) tensor as a single-GPU run."""
     import torch.distributed as dist
     n = len(eot)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return engine.text_features(eot, split)
+    # a process group of ONE rank still takes the collective: the launch shapes and the RCCL call are then the same code at every N
     world, rank = dist.get_world_size(), dist.get_rank()
     per = -(-n // world)
     lo, hi = min(rank * per, n), min((rank + 1) * per, n)
