@@ -386,7 +386,8 @@ template <int HD, int NW, int MODE, bool CAUSAL>
 int launch_split(const AttnParams& p, hipStream_t s) {
     const int sq = p.a.split_qk, sp = p.a.split_pv;
     // split 2 (include/cvlm.h) has kernels for the ViT-H geometries only: everywhere else it runs as split 3, which holds its products and more
-    if ((sq == 3 && sp == 3) || (sq == 2 && sp == 2)) return launch<HD, NW, MODE, 3, 3, CAUSAL>(p, s);
+    // (1, 2) -- K's and Q's hi planes in the scores, round 6 -- likewise
+    if ((sq == 3 && sp == 3) || (sq == 2 && sp == 2) || (sq == 1 && sp == 2)) return launch<HD, NW, MODE, 3, 3, CAUSAL>(p, s);
     if (sq == 3 && sp == 1) return launch<HD, NW, MODE, 3, 1, CAUSAL>(p, s);
     if (sq == 1 && sp == 1) return launch<HD, NW, MODE, 1, 1, CAUSAL>(p, s);
     return CVLM_E_UNSUPPORTED;
@@ -425,7 +426,8 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     if (!g.relh_hi || !g.relw_hi || (g.split_qk >= 2 && (!g.relh_lo || !g.relw_lo))) return CVLM_E_BADARG;
     if (g.grid <= 0 || g.S != g.grid * g.grid) return CVLM_E_BADARG;
     if (g.mode == 1) {
-        if ((g.grid == 64 || g.grid == 96) && g.split_qk == g.split_pv && g.split_qk >= 2) {   // 1024^2 / 1536^2 SAM geometries, parity modes
+        const bool parity_split = (g.split_qk == g.split_pv && g.split_qk >= 2) || (g.split_qk == 1 && g.split_pv == 2);
+        if ((g.grid == 64 || g.grid == 96) && parity_split) {   // 1024^2 / 1536^2 SAM geometries, parity modes
             const int rc = cvlm_attention_global64_pp(g, s);
             if (rc != CVLM_E_UNSUPPORTED) return rc;                           // incl. CVLM_E_WORKSPACE: a missing workspace is an error, not a silent fallback
         }
@@ -434,7 +436,8 @@ extern "C" int cvlm_attention(const cvlm_attn_args* args, void* stream) {
     }
     if (g.mode == 2) {
         if (g.window <= 0 || !g.pad_hi || ((g.split_qk >= 2 || g.split_pv >= 2) && !g.pad_lo)) return CVLM_E_BADARG;
-        if (g.window == 14 && g.split_qk == g.split_pv && g.split_qk >= 2 && g.out_lo) return cvlm_attention_window14_pc(g, s);   // SAM window geometry, parity modes
+        const bool parity_split = (g.split_qk == g.split_pv && g.split_qk >= 2) || (g.split_qk == 1 && g.split_pv == 2);
+        if (g.window == 14 && parity_split && g.out_lo) return cvlm_attention_window14_pc(g, s);   // SAM window geometry, parity modes
         p.L = g.window; p.LTP = g.window | 1;
         p.nwx = (g.grid + g.window - 1) / g.window;
         p.S_seq = g.window * g.window;

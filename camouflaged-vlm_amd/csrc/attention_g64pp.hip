@@ -51,8 +51,10 @@ __device__ __forceinline__ void phase_barrier() {
 
 // PLO / QLO: the lo planes of P and of Q take part in their products (cvlm_attn_args.split_pv / split_qk == 3); false: two MFMAs per product,
 // P as ONE fp16 per probability (rounded to nearest, the softmax denominator summed from the rounded values by a ones-row product), Q
-// as its hi plane (split == 2: see include/cvlm.h)
-template <int L, bool PLO, bool QLO>
+// as its hi plane (split == 2: see include/cvlm.h).  KLO == false (split_qk == 1, round 6): K's lo plane stays out too -- ONE MFMA per
+// k-step of the scores, and the plane is neither fetched nor read (profiles/r06_probe_kv_lo.log: fp16(k) costs the masks 4e-5; the
+// rel-pos tables keep their three terms).  V always enters with both planes (fp16(v) alone costs 4e-4).
+template <int L, bool PLO, bool QLO, bool KLO>
 __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
                                                             const half_t* __restrict__ vt_lo) {
     // L = side of the token map (64: 1024^2 images, 96: 1536^2).  A key row is TPR = L / 32 tiles; the 96 map needs a
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             const int pl = i / 6, sub = i - pl * 6;
             const int c = sub * 64 + lane;
             int row = c / 11, ch = c - row * 11;
-            dok[j] = row < KT;                                       // the K image ends at chunk 352
+            dok[j] = row < KT && (KLO || pl == 0);                   // the K image ends at chunk 352; without K's lo plane waves 2, 3 carry nothing
             if (row >= KT) row = KT - 1;
             if (ch >= 10) ch = 0;
             dsrc[j] = (pl ? qkv_lo : qkv_hi) + qkv_offset(QS, b, row, 1, head) + ch * 8;
@@ -215,9 +217,11 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const half8 kh = *(const half8*)(kr + 16 * ks);
-            const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
-            if constexpr (CVLM_ATTN_K_LO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+            if constexpr (KLO) {
+                const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+            }
             if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
         }
     };
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
             } else {
                 constexpr int ks = I - NDB;
                 fa[I % RS] = *(const half8*)(kr + 16 * ks);
-                fb[I % RS] = *(const half8*)(kr + KPL + 16 * ks);
+                if constexpr (KLO) fb[I % RS] = *(const half8*)(kr + KPL + 16 * ks);
             }
         };
         auto compute = [&](auto ic) {
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
                     const half8 bh = __builtin_bit_cast(half8, xh[qb]), bl = __builtin_bit_cast(half8, xl[qb]);
                     if constexpr (!PLO && I == 0) osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8(), bh, osum[qb], 0, 0, 0);
                     o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[I][qb], 0, 0, 0);
-                    if constexpr (CVLM_ATTN_V_LO) o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[I][qb], 0, 0, 0);
+                    o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[I][qb], 0, 0, 0);
                     if constexpr (PLO) o[I][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[I][qb], 0, 0, 0);
                 }
             } else {
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
                     for (int r = 0; r < 16; ++r) s[r] = 0.f;
                 }
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s, 0, 0, 0);
-                if constexpr (CVLM_ATTN_K_LO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s, 0, 0, 0);
+                if constexpr (KLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s, 0, 0, 0);
                 if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s, 0, 0, 0);
             }
         };
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pp_kernel(const cvlm_attn_args
 // The P values leave the softmax in the 32x32 accumulator layout (lane = (query, half), 16 keys); one v_permlane16_swap per
 // register pair turns them into the two B operands of the 16-wide shape (queries 0-15 / 16-31 of the wave, four key groups of
 // eight), V^T is stored in the matching key order by transpose_v_kernel.
-template <bool PLO, bool QLO>
+template <bool PLO, bool QLO, bool KLO>
 __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_args g, const half_t* __restrict__ vt_hi,
                                                               const half_t* __restrict__ vt_lo) {
     constexpr int L = 64, HD = 80, KS = 5, NDB = 5, KP = 88, KT = 32, LTP = L + 1, S = L * L, NTILE = S / KT, NPAIR = NTILE / 2;
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
             const int pl = i / 6, sub = i - pl * 6;
             const int c = sub * 64 + lane;
             int row = c / 11, ch = c - row * 11;
-            dok[j] = row < KT;
+            dok[j] = row < KT && (KLO || pl == 0);
             if (row >= KT) row = KT - 1;
             if (ch >= 10) ch = 0;
             dsrc[j] = (pl ? qkv_lo : qkv_hi) + qkv_offset(QS, b, row, 1, head) + ch * 8;
@@ -580,9 +584,11 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const half8 kh = *(const half8*)(kr + 16 * ks);
-                const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[e], 0, 0, 0);
-                if constexpr (CVLM_ATTN_K_LO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[e], 0, 0, 0);
+                if constexpr (KLO) {
+                    const half8 kl = *(const half8*)(kr + KPL + 16 * ks);
+                    s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[e], 0, 0, 0);
+                }
                 if constexpr (QLO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[e], 0, 0, 0);
             }
         }
@@ -597,7 +603,11 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
         // "stage I's two fragments have arrived".
         const unsigned va = (unsigned)(size_t)(LDS_AS const unsigned char*)(Vring + vslot0 * VSLOT_B) + (unsigned)v_lane_off;
         unsigned ka = (unsigned)(size_t)(LDS_AS const unsigned char*)(Kring + kslot0 * KSLOT_B) + 2u * (unsigned)k_lane_off;
-        constexpr int PD = CVLM_G64_PD, RS = PD + 1, NPV = 2 * NDB, NST = NPV + 10;
+        // KLO == false: the score stages carry TWO k-steps of K's hi plane each (k-steps 2n and 2n + 1 of the pair's ten) instead of one
+        // k-step of both planes: every stage still requests exactly two fragments -- the counted waits below stay `2 * ahead`, and no
+        // fragment is requested that no MFMA consumes (an asm read whose result is dead leaves its register to the allocator while the
+        // read is still in flight: that is what broke the `k` / `v` probe builds of round 5, profiles/r06_probe_kv_lo.log)
+        constexpr int PD = CVLM_G64_PD, RS = PD + 1, NPV = 2 * NDB, NKS = KLO ? 10 : 5, NST = NPV + NKS;
         half8 fa[RS], fb[RS];
         auto load = [&](auto ic) {
             constexpr int I = decltype(ic)::value;
@@ -607,11 +617,16 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                 constexpr int off = e * VSLOT_B + (16 * db) * VROW_B;
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[I % RS]) : "v"(a_v), "n"(off));
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I % RS]) : "v"(a_v), "n"(off + VPL_B));
-            } else {
+            } else if constexpr (KLO) {
                 constexpr int e = (I - NPV) / 5, ks = (I - NPV) % 5;
                 constexpr int off = e * KSLOT_B + 32 * ks;
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[I % RS]) : "v"(a_k), "n"(off));
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I % RS]) : "v"(a_k), "n"(off + KPL_B));
+            } else {
+                constexpr int i0 = 2 * (I - NPV), i1 = i0 + 1;
+                constexpr int off0 = (i0 / 5) * KSLOT_B + 32 * (i0 % 5), off1 = (i1 / 5) * KSLOT_B + 32 * (i1 % 5);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[I % RS]) : "v"(a_k), "n"(off0));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[I % RS]) : "v"(a_k), "n"(off1));
             }
         };
         auto compute = [&](auto ic) {
@@ -624,18 +639,32 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
                     const half8 bh = __builtin_bit_cast(half8, xh[e][qb]), bl = __builtin_bit_cast(half8, xl[e][qb]);
                     if constexpr (!PLO && db == 0) osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones8(), bh, osum[qb], 0, 0, 0);
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bh, o[db][qb], 0, 0, 0);
-                    if constexpr (CVLM_ATTN_V_LO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[db][qb], 0, 0, 0);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq, bh, o[db][qb], 0, 0, 0);
                     if constexpr (PLO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bl, o[db][qb], 0, 0, 0);
                 }
-            } else {
+            } else if constexpr (KLO) {
                 constexpr int e = (I - NPV) / 5, ks = (I - NPV) % 5;
                 if constexpr (ks == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[e][r] = 0.f;
                 }
                 s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[ks], s[e], 0, 0, 0);
-                if constexpr (CVLM_ATTN_K_LO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s[e], 0, 0, 0);
+                s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[ks], s[e], 0, 0, 0);
                 if constexpr (QLO) s[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ql[ks], s[e], 0, 0, 0);
+            } else {
+                static_assert(KLO || !QLO, "one-term scores: K's and Q's hi planes");
+                constexpr int i0 = 2 * (I - NPV), i1 = i0 + 1;
+                constexpr int e0 = i0 / 5, k0 = i0 % 5, e1 = i1 / 5, k1 = i1 % 5;
+                if constexpr (k0 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[e0][r] = 0.f;
+                }
+                s[e0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qh[k0], s[e0], 0, 0, 0);
+                if constexpr (k1 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[e1][r] = 0.f;
+                }
+                s[e1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq, qh[k1], s[e1], 0, 0, 0);
             }
         };
         load(std::integral_constant<int, 0>{});
@@ -663,9 +692,12 @@ __global__ __launch_bounds__(512, 2) void attn_g64pair_kernel(const cvlm_attn_ar
         stage(std::integral_constant<int, 8>{}); stage(std::integral_constant<int, 9>{});
         stage(std::integral_constant<int, 10>{}); stage(std::integral_constant<int, 11>{});
         stage(std::integral_constant<int, 12>{}); stage(std::integral_constant<int, 13>{});
-        stage(std::integral_constant<int, 14>{}); stage(std::integral_constant<int, 15>{});
-        stage(std::integral_constant<int, 16>{}); stage(std::integral_constant<int, 17>{});
-        stage(std::integral_constant<int, 18>{}); stage(std::integral_constant<int, 19>{});
+        stage(std::integral_constant<int, 14>{});
+        if constexpr (NST == 20) {
+            stage(std::integral_constant<int, 15>{});
+            stage(std::integral_constant<int, 16>{}); stage(std::integral_constant<int, 17>{});
+            stage(std::integral_constant<int, 18>{}); stage(std::integral_constant<int, 19>{});
+        }
     };
     // X(q): online softmax over the 64 keys of key row q (both tiles share the row bias th; the column bias is per tile)
     auto X = [&](float th) {
@@ -838,7 +870,8 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const cvlm_attn_args g
 
 // ---- V^T workspace: caller-owned (cvlm_attn_args.workspace, size from cvlm_attention_workspace_bytes())
 int64_t cvlm_attention_global64_pp_workspace_bytes(const cvlm_attn_args& g) {
-    if (g.mode != 1 || g.hd != 80 || g.split_qk != g.split_pv || (g.split_qk != 3 && g.split_qk != 2) || (g.grid != 64 && g.grid != 96)) return 0;
+    const bool splits = (g.split_qk == 3 && g.split_pv == 3) || (g.split_qk == 2 && g.split_pv == 2) || (g.split_qk == 1 && g.split_pv == 2);
+    if (g.mode != 1 || g.hd != 80 || !splits || (g.grid != 64 && g.grid != 96)) return 0;
     return (int64_t)2 * g.B * g.heads * 80 * g.grid * g.grid * (int64_t)sizeof(half_t);
 }
 
@@ -847,8 +880,8 @@ extern "C" int cvlm_debug_set_attn_g64_trace(void* buf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_g64_trace), &buf, sizeof(buf));
 }
 
-// split 3/3 (PLO = QLO = true) or 2/2 form of cvlm_attention_global64()
-template <int L, bool PLO, bool QLO>
+// split 3/3 (PLO = QLO = KLO = true), 2/2 (K's lo plane only) or 1/2 (no lo plane in the scores) form of cvlm_attention_global64()
+template <int L, bool PLO, bool QLO, bool KLO>
 static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int S = L * L;
     constexpr int smem = 3 * (2 * 5632) + (L == 64 ? 3 : 2) * (2 * 6144) + 256 * (L + 1) * 4;
@@ -861,29 +894,25 @@ static int launch_pp(const cvlm_attn_args& g, hipStream_t s) {
         constexpr int smem2 = 4 * (2 * 5632) + 4 * (2 * 6144) + 256 * (L + 1) * 4;
         static bool attr2[16] = {};
         if (cvlm_first_on_device(attr2))
-            (void)hipFuncSetAttribute((const void*)attn_g64pair_kernel<PLO, QLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
-        hipLaunchKernelGGL((attn_g64pair_kernel<PLO, QLO>), dim3(S / 256, g.heads, g.B), dim3(512), smem2, s, g, (const half_t*)vt,
+            (void)hipFuncSetAttribute((const void*)attn_g64pair_kernel<PLO, QLO, KLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+        hipLaunchKernelGGL((attn_g64pair_kernel<PLO, QLO, KLO>), dim3(S / 256, g.heads, g.B), dim3(512), smem2, s, g, (const half_t*)vt,
                            (const half_t*)(vt + plane));
     } else {                                                          // 96 x 96 map: one 32-key tile per phase
         static bool attr[16] = {};
         if (cvlm_first_on_device(attr))
-            (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L, PLO, QLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        hipLaunchKernelGGL((attn_g64pp_kernel<L, PLO, QLO>), dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
+            (void)hipFuncSetAttribute((const void*)attn_g64pp_kernel<L, PLO, QLO, KLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipLaunchKernelGGL((attn_g64pp_kernel<L, PLO, QLO, KLO>), dim3(S / 256, g.heads, g.B), dim3(512), smem, s, g, (const half_t*)vt,
                            (const half_t*)(vt + plane));
     }
     CVLM_CHECK_LAUNCH();
     return 0;
 }
 
-// global attention on a 64x64 or 96x96 token map: split 3/3 (hi/lo operands on both sides of both products) or 2/2
+// global attention on a 64x64 or 96x96 token map: split 3/3 (hi/lo operands on both sides of both products), 2/2, or 1/2
 int cvlm_attention_global64_pp(const cvlm_attn_args& g, hipStream_t s) {
-    const bool full = g.split_qk == 3 && g.split_pv == 3;
-    if (!full && !(g.split_qk == 2 && g.split_pv == 2)) return CVLM_E_UNSUPPORTED;
-    if constexpr (CVLM_ATTN_TERMS >= 0) {                            // probe builds: the build names the terms
-        constexpr bool P = (CVLM_ATTN_TERMS & 1) != 0, Q = (CVLM_ATTN_TERMS & 2) != 0;
-        return g.grid == 64 ? launch_pp<64, P, Q>(g, s) : g.grid == 96 ? launch_pp<96, P, Q>(g, s) : CVLM_E_UNSUPPORTED;
-    }
-    if (g.grid == 64) return full ? launch_pp<64, true, true>(g, s) : launch_pp<64, false, false>(g, s);
-    if (g.grid == 96) return full ? launch_pp<96, true, true>(g, s) : launch_pp<96, false, false>(g, s);
+    const bool full = g.split_qk == 3 && g.split_pv == 3, two = g.split_qk == 2 && g.split_pv == 2, one = g.split_qk == 1 && g.split_pv == 2;
+    if (!full && !two && !one) return CVLM_E_UNSUPPORTED;
+    if (g.grid == 64) return full ? launch_pp<64, true, true, true>(g, s) : two ? launch_pp<64, false, false, true>(g, s) : launch_pp<64, false, false, false>(g, s);
+    if (g.grid == 96) return full ? launch_pp<96, true, true, true>(g, s) : two ? launch_pp<96, false, false, true>(g, s) : launch_pp<96, false, false, false>(g, s);
     return CVLM_E_UNSUPPORTED;
 }

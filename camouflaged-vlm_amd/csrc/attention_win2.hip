@@ -76,8 +76,9 @@ __device__ unsigned long long* g_win2_trace = nullptr;
 #define WIN2_STAMP(x) do { } while (0)
 #endif
 
-// PLO / QLO: as in attention_g64pp.hip (split 3: true; split 2: one fp16 per probability, Q's hi plane)
-template <bool PLO, bool QLO>
+// PLO / QLO / KLO: as in attention_g64pp.hip (split 3: all true; split 2: one fp16 per probability, Q's hi plane; split_qk 1: K's hi plane
+// too -- its lo plane is then not fetched: the producer's K batches are one plane)
+template <bool PLO, bool QLO, bool KLO>
 __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_args g, const int nwx, const int npairs) {
     constexpr int HD = 80, KS = 5, NDB = 5, CPR = 10, KP = 80, VP = 80, L = 14, S_SEQ = 196;
     constexpr int KT = 32, NKT = 7, NCW = 7;                        // 7 key tiles, 7 consumer waves
@@ -155,9 +156,11 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                 src[sub][1] = src[sub][0] + disp;
             }
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int pl = 0; pl < 2; ++pl) {
+                if (!KLO && pl == 1 && op == 0) continue;             // K's lo plane is not multiplied: not fetched (op is a literal at every call)
 #pragma unroll
                 for (int sub = 0; sub < IPP; ++sub) glds16(src[sub][pl], dst + pl * PLANE_B + sub * 1024);
+            }
         };
         // once: rel-pos tables (4 planes back to back, 17 pieces) and the one-hot block (14 pieces)
         {
@@ -200,8 +203,10 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
             if (ik) issue_tile(0, kn);
             if (iv) issue_tile(1, vn);
             // everything but the batch just issued has landed -> K(gt + 2), V(gt + 1) are there when we arrive at B_(gt+1)
-            if (ik && iv) wait_vm<4 * IPP>();
-            else if (ik || iv) wait_vm<2 * IPP>();
+            constexpr int KB = (KLO ? 2 : 1) * IPP, VB = 2 * IPP;      // DMA instructions of a K / V batch
+            if (ik && iv) wait_vm<KB + VB>();
+            else if (ik) wait_vm<KB>();
+            else if (iv) wait_vm<VB>();
             else wait_vm<0>();
         }
         return;
@@ -338,9 +343,11 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const half8 kh = *(const half8*)(kr + 16 * ks);
-                const half8 kl = *(const half8*)(kr + PLANE_B / 2 + 16 * ks);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
-                if constexpr (CVLM_ATTN_K_LO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                if constexpr (KLO) {
+                    const half8 kl = *(const half8*)(kr + PLANE_B / 2 + 16 * ks);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+                }
                 if constexpr (QLO) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
             }
             const int row = t * KT + qc;
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
                         osum[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(half8{one, one, one, one, one, one, one, one}, bh, osum[qb], 0, 0, 0);
                     }
                     o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bh, o[db][qb], 0, 0, 0);
-                    if constexpr (CVLM_ATTN_V_LO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, bh, o[db][qb], 0, 0, 0);
+                    o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, bh, o[db][qb], 0, 0, 0);
                     if constexpr (PLO) o[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, bl, o[db][qb], 0, 0, 0);
                 }
             };
@@ -544,29 +551,29 @@ __global__ __launch_bounds__(512, 1) void attn_win14p_kernel(const cvlm_attn_arg
 extern "C" int cvlm_debug_set_attn_win2_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_win2_trace), &buf, sizeof(buf)); }
 #endif
 
-// split 3/3 or 2/2, producer / consumer form; called from cvlm_attention() for the SAM window geometry
-template <bool PLO, bool QLO>
+// split 3/3, 2/2 or 1/2, producer / consumer form; called from cvlm_attention() for the SAM window geometry
+template <bool PLO, bool QLO, bool KLO>
 static int launch_win14(const cvlm_attn_args& g, hipStream_t s) {
     constexpr int smem = 6 * 10240 + 17 * 1024 + 224 * 32 * 2 + 2 * (2 * 224 * 8) + 224 * 17 * 4;
     const int nwx = (g.grid + 13) / 14;
     const int npairs = g.heads * g.B * nwx * nwx;
     static bool attr[16] = {};
     if (cvlm_first_on_device(attr))
-        (void)hipFuncSetAttribute((const void*)attn_win14p_kernel<PLO, QLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_win14p_kernel<PLO, QLO, KLO>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     static int cus_[16] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     int& cus = cus_[dev & 15];
     if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const int wgs = npairs < cus ? npairs : cus;
-    hipLaunchKernelGGL((attn_win14p_kernel<PLO, QLO>), dim3(wgs), dim3(512), smem, s, g, nwx, npairs);
+    hipLaunchKernelGGL((attn_win14p_kernel<PLO, QLO, KLO>), dim3(wgs), dim3(512), smem, s, g, nwx, npairs);
     CVLM_CHECK_LAUNCH();
     return 0;
 }
 
 int cvlm_attention_window14_pc(const cvlm_attn_args& g, hipStream_t s) {
-    if constexpr (CVLM_ATTN_TERMS >= 0) return launch_win14<(CVLM_ATTN_TERMS & 1) != 0, (CVLM_ATTN_TERMS & 2) != 0>(g, s);   // probe builds (common.h)
-    if (g.split_qk == 3 && g.split_pv == 3) return launch_win14<true, true>(g, s);
-    if (g.split_qk == 2 && g.split_pv == 2) return launch_win14<false, false>(g, s);
+    if (g.split_qk == 3 && g.split_pv == 3) return launch_win14<true, true, true>(g, s);
+    if (g.split_qk == 2 && g.split_pv == 2) return launch_win14<false, false, true>(g, s);
+    if (g.split_qk == 1 && g.split_pv == 2) return launch_win14<false, false, false>(g, s);
     return CVLM_E_UNSUPPORTED;
 }

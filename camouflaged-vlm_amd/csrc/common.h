@@ -160,13 +160,4 @@ static inline bool cvlm_first_on_device(bool (&done)[16]) {
     return first;
 }
 
-// Probe builds of the ViT-H attention kernels (tools/ab_attn_terms.sh, profiles/r05_precision_sensitivity.log): which lo planes take part in
-// the two products, whatever split_qk / split_pv say.  Bit 0: P, 1: Q, 2: K, 3: V.  -1 (the product build): P and Q by split (3: in, 2: out),
-// K and V always in.
-#ifndef CVLM_ATTN_TERMS
-#define CVLM_ATTN_TERMS -1
-#endif
-constexpr bool CVLM_ATTN_K_LO = CVLM_ATTN_TERMS < 0 || (CVLM_ATTN_TERMS & 4) != 0;
-constexpr bool CVLM_ATTN_V_LO = CVLM_ATTN_TERMS < 0 || (CVLM_ATTN_TERMS & 8) != 0;
-
 #define CVLM_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -136,7 +136,7 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
     // (For grids of several rounds whose last round is partial -- proj / lin2 of a batch of 8 -- the same split measured slower,
     // profiles/r03_colsplit_ab.log; that form is gone.)
     if (!in_colsplit && colsplit_env && g.split == 3 && !conv && g.batch <= 1 && g.hm_S == 0 && g.ps_c2 == 0 && variant_env == 0 &&
-        g.M <= 4096 && !h2res && !g.a_mx) {
+        g.M <= 4096 && !h2res && !g.a_mx && !g.out_mx) {   // (an mx image's groups and scale bytes do not move with a plain column offset: ADVICE r5)
         const int nby = (g.M + 255) / 256, nbx = (g.N + 255) / 256;
         const int c0 = nby > 0 ? 256 / nby : 0;                          // column tiles of the first launch: one round of tiles
         const int rest_ = g.N - c0 * 256;
@@ -427,8 +427,11 @@ extern "C" int cvlm_gemm(const cvlm_gemm_args* args, void* stream) {
             // both operands mx: the staggered 256-column kernel in its unit form (gemm_kernel.h, MX), one instantiation per epilogue form;
             // 192-row tiles under one round of 256-row ones (the h2-residual form, as above); K-parts of a partial last round are whole
             // groups of 8 units
-            if (!lds_staged || p.a.batch != 1 || (g.M & 7) || (g.N & 7) || (int64_t)g.M * g.lda * 2 >= ((int64_t)1 << 32) ||
-                (int64_t)g.N * g.ldw_mx * 2 >= ((int64_t)1 << 32))
+            // 32-bit quantities of the kernel: the offset of a row inside its 8-row DMA block (the block's base is a 64-bit scalar) and the
+            // byte offset of a row's scale words -- not the size of the images (batches above 4 GiB of operand are fine)
+            if (!lds_staged || p.a.batch != 1 || (g.M & 7) || (g.N & 7) || (int64_t)8 * g.lda * 2 >= ((int64_t)1 << 32) ||
+                (int64_t)8 * g.ldw_mx * 2 >= ((int64_t)1 << 32) || (int64_t)g.M * 4 * g.lda_s >= ((int64_t)1 << 32) ||
+                (int64_t)g.N * 4 * g.ldw_s >= ((int64_t)1 << 32))
                 return CVLM_E_UNSUPPORTED;
             const long t5 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256), t6 = (long)((g.M + 191) / 192) * ((g.N + 255) / 256);
             const bool use192 = t192_env && h2res && t5 <= 256 && t6 <= 256 && t6 > t5 && g.M > 4096;

@@ -972,9 +972,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
             const int mw = e_bm + wm * WROWS;                           // first row of this wave
             int64_t hm_col = 0, hm_bstride = 0;
             int hm_b = 0, hm_t = 0;                                   // image / token of row mw + rowh
+            bool hm_lo = true;                                        // ABI 12, hm_nolo: this lane's columns are in a third (q / k / v) whose lo plane nobody reads
             if (g.hm_S > 0) {                                         // head-major qkv store (8 | hd): column part once
                 const int Dh = g.hm_H * g.hm_hd;
                 const int which = nh / Dh, r2 = nh - which * Dh, h = r2 / g.hm_hd, d = r2 - h * g.hm_hd;
+                hm_lo = ((g.hm_nolo >> which) & 1) == 0;
                 hm_bstride = (int64_t)g.hm_H * g.hm_S * g.hm_hd;
                 hm_col = (int64_t)which * (g.M / g.hm_S) * hm_bstride + (int64_t)h * g.hm_S * g.hm_hd + d;
                 hm_b = (mw + rowh) / g.hm_S;
@@ -1193,7 +1195,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                             } else {
                                 *(half8*)((half_t*)g.out_hi + zh + off) = hi;
                                 if (g.out_il) *(half8*)((half_t*)g.out_hi + zh + off + 32) = lo;
-                                else if (g.out_lo) *(half8*)((half_t*)g.out_lo + zh + off) = lo;
+                                else if (g.out_lo && hm_lo) *(half8*)((half_t*)g.out_lo + zh + off) = lo;
                             }
                         }
                     }
@@ -1282,6 +1284,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 for (int j = 0; j < 4; ++j) v[j] = fabsf(v[j]);
             }
             int64_t off_f, off_h;
+            bool slow_lo = true;                                        // hm_nolo (see the LDS-staged path)
             if (g.ps_c2 > 0) {
                 const int dy = n / g.ps_c2, r = n - dy * g.ps_c2;
                 off_f = off_h = ps_base + (int64_t)dy * (2 * g.ps_w) * (g.ps_c2 >> 1) + r;
@@ -1293,6 +1296,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                     const int which = n / Dh, r = n - which * Dh, h = r / g.hm_hd, d = r - h * g.hm_hd;
                     const int bi = m / g.hm_S, tk = m - bi * g.hm_S;
                     off_h = ((((int64_t)which * (g.M / g.hm_S) + bi) * g.hm_H + h) * g.hm_S + tk) * g.hm_hd + d;
+                    slow_lo = ((g.hm_nolo >> which) & 1) == 0;
                 }
             }
             if (g.out_f32 && DBG != 3) {
@@ -1309,7 +1313,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
 #pragma unroll
                 for (int j = 0; j < 4; ++j) split_h2(v[j] * oscale, hi[j], lo[j]);
                 half_t* oh = (half_t*)g.out_hi + (int64_t)z * g.stride_oh + off_h;
-                half_t* ol = g.out_lo ? (half_t*)g.out_lo + (int64_t)z * g.stride_oh + off_h : nullptr;
+                half_t* ol = (g.out_lo && slow_lo) ? (half_t*)g.out_lo + (int64_t)z * g.stride_oh + off_h : nullptr;
                 if (full && vec_h && ((off_h & 3) == 0)) {
                     *(half4*)oh = half4{hi[0], hi[1], hi[2], hi[3]};
                     if (ol) *(half4*)ol = half4{lo[0], lo[1], lo[2], lo[3]};

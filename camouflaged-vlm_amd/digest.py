@@ -2,7 +2,7 @@
 written by tools/make_golden.py from /root/reference, one B = 1 forward per image): shared by bench.py and tests/.
 
 Gate (BASELINE.json north_star): mask logits and class logits within 1e-3 abs of the reference's fp32 CPU forward on the
-sampled positions, mask IoU >= 0.999 on the full-resolution sign bits, identical predictions -- for EVERY image handed in.
+sampled positions (4096 common ones; from round 6 on also 65536 more and each image's 4096 pixels nearest the decision boundary), mask IoU >= 0.999 on the full-resolution sign bits, identical predictions -- for EVERY image handed in.
 Checker code only: nothing here runs on the product path."""
 from __future__ import annotations
 
@@ -47,8 +47,13 @@ def check_cascade(masks, pred, logits, dg: Dict[str, np.ndarray], image_ids: Seq
         ref_bits = np.unpackbits(dg["mask_bits"][iid])[:mb.size].astype(bool)
         got_bits = mb > 0
         inter, union = float((got_bits & ref_bits).sum()), float((got_bits | ref_bits).sum())
-        rec = {"image": int(iid), "iou": inter / max(union, 1.0),
-               "mask_err": float(np.abs(mb[dg["sample_idx"]] - dg["mask_samples"][iid]).max()),
+        # mask logits: the 4096 common positions of rounds 1-5, and (digests written from round 6 on) 65536 more common positions and the
+        # image's own 4096 positions of smallest |logit| -- where the arithmetic could flip a sign
+        errs = {"sparse": float(np.abs(mb[dg["sample_idx"]] - dg["mask_samples"][iid]).max())}
+        if "dense_idx" in dg:
+            errs["dense"] = float(np.abs(mb[dg["dense_idx"]] - dg["dense_samples"][iid]).max())
+            errs["near"] = float(np.abs(mb[dg["near_idx"][iid]] - dg["near_samples"][iid]).max())
+        rec = {"image": int(iid), "iou": inter / max(union, 1.0), "mask_err": max(errs.values()), "mask_err_sets": errs,
                "logit_err": float(np.abs(lg[b] - dg["class_logits"][iid]).max()),
                "pred_equal": int(pr[b]) == int(dg["pred"][iid])}
         if p1 is not None:
@@ -60,6 +65,8 @@ def check_cascade(masks, pred, logits, dg: Dict[str, np.ndarray], image_ids: Seq
     out = {"checked_images": checked, "min_iou": min(r["iou"] for r in per),
            "max_abs_mask_err": max(r["mask_err"] for r in per), "max_abs_class_logit_err": max(r["logit_err"] for r in per),
            "pred_equal": all(r["pred_equal"] for r in per), "tolerance": TOL, "iou_min": IOU_MIN}
+    out["mask_positions_per_image"] = int(dg["sample_idx"].size + (dg["dense_idx"].size + dg["near_idx"].shape[1] if "dense_idx" in dg else 0))
+    out["max_abs_mask_err_by_set"] = {k: max(r["mask_err_sets"][k] for r in per) for k in per[0]["mask_err_sets"]}
     if p1 is not None:
         out["max_abs_pass1_logit_err"] = max(r["pass1_logit_err"] for r in per)
     out["ok"] = bool(out["min_iou"] >= IOU_MIN and out["max_abs_mask_err"] <= TOL and out["max_abs_class_logit_err"] <= TOL and

@@ -10,6 +10,7 @@ f32 for residual streams and module outputs, h2 (split-half planes) for every GE
 """
 from __future__ import annotations
 
+import dataclasses
 import math
 import os
 from dataclasses import dataclass
@@ -25,12 +26,15 @@ from .spec import ClipGeometry, SamGeometry
 
 @dataclass(frozen=True)
 class Precision:
-    """split = 3: hi*hi + lo*hi + hi*lo products (fp32-grade, the parity mode); 1: fp16 operands.
+    """split = 3: hi*hi + lo*hi + hi*lo products (~22 significant bits per operand, the reference-grade mode `exact`); 1: fp16 operands.
     mx: the GEMMs whose operands only GEMMs touch (qkv / lin1 / lin2 of the ViT-H blocks, the CLIP MLPs) form the two correction products
     lo*hi and hi*lo on the block-scaled e4m3 matrix instruction (include/cvlm.h ABI 10); the other GEMMs are split = 3.
-    qk / pv = 2 (ABI 11, the ViT-H attention kernels): the products keep the lo planes of K and V and drop those of Q and of the
-    probabilities (one fp16 per probability, the softmax denominator summed from the rounded values): two MFMAs per product instead of three.
-    `mx` = both economies, on batches of two or more images; one image per call runs the `exact` arithmetic (SamEncoder.attn_split)."""
+    qk / pv (the ViT-H attention kernels): (2, 2), ABI 11 -- the products keep the lo planes of K and V and drop those of Q and of the
+    probabilities (one fp16 per probability, the softmax denominator summed from the rounded values); (1, 2), ABI 12 -- K enters the
+    scores as its hi plane too: ONE MFMA per k-step of q.k^T, two per step of P.v.
+    `mx` = the mx GEMMs + (1, 2) attention, on batches of two or more images; one image per call runs the `exact` arithmetic
+    (SamEncoder.attn_split), and a batch's first use of the mode on a set of weights is preceded by Cascade._mx_self_check.
+    `mx22` / `mx33`: the mx GEMMs with (2, 2) / (3, 3) attention (A/B modes of bench.py)."""
     gemm: int = 3
     qk: int = 3
     pv: int = 3
@@ -38,8 +42,8 @@ class Precision:
 
     @staticmethod
     def named(name: str) -> "Precision":
-        return {"exact": Precision(3, 3, 3), "mx": Precision(3, 2, 2, True), "mx33": Precision(3, 3, 3, True), "fast": Precision(1, 1, 1),
-                "mixed": Precision(3, 3, 1)}[name]
+        return {"exact": Precision(3, 3, 3), "mx": Precision(3, 1, 2, True), "mx33": Precision(3, 3, 3, True), "mx22": Precision(3, 2, 2, True),
+                "mx12": Precision(3, 1, 2, True), "fast": Precision(1, 1, 1), "mixed": Precision(3, 3, 1)}[name]
 
 
 # Static power-of-two scales that keep UNBOUNDED activations inside fp16 range when they become h2 GEMM operands
@@ -468,7 +472,8 @@ class SamEncoder(_Base):
         sq, sp = self.attn_split(M)
         for i, blk in enumerate(self.blocks):
             hip.ln_stats_merge(pcs, M, D, 1e-6, mrg, gws)
-            self.gemm(xh, blk["qkv_f"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim), alpha=inv,
+            # split_qk == 1: the attention kernels read K's hi plane only -- the projection does not write the other (a sixth of its stores)
+            self.gemm(xh, blk["qkv_f"], M, out_h2=qkv, head_major=(T, g.num_heads, g.head_dim), head_major_nolo=2 if sq == 1 else 0, alpha=inv,
                       ln_fold=(mrg, blk["qkv_f"].colsum))
             if blk["window"] > 0:
                 self.attention(qkv, att, B, T, g.num_heads, g.head_dim, mode=2, grid=G, window=blk["window"],
@@ -1171,6 +1176,39 @@ class Cascade(_Base):
         self._done = [None, None]                                    # side-stream completion events of the last two batches
         self._parity = 0
         self._guard, self._guard_host, self._guard_free, self._refused_seen, self.fold_refusals = [], None, [], 0, 0
+        # precision `mx` is an economy measured on synthetic weights: the first batch that would take it is preceded by a self-check on THESE weights
+        self.mx_self_check = os.environ.get("CVLM_MX_SELF_CHECK", "1") != "0"
+        self.mx_self_check_result: Optional[dict] = None
+
+    # ---- precision `mx` self-check -----------------------------------------------------------------------
+    # The mx arithmetic (e4m3 correction products, one-term q.k^T, P as one f16) was adopted on the evidence of synthetic weights.  A
+    # checkpoint nobody has measured gets a measurement of its own: before the first batch of two or more images (the forwards that take
+    # the mx path; one image per call runs the `exact` arithmetic anyway, SamEncoder.attn_split) the engine runs the first two images as a
+    # batch (mx) and image 0 alone (exact) and compares every mask logit and the prediction of image 0.  Beyond MX_SELF_CHECK_TOL -- 3/4 of
+    # the 1e-3 gate, the exact arithmetic itself sitting 5e-5 from the reference -- or with another prediction, it says so and serves
+    # every later forward in `exact`.  Cost: one B = 2 and one B = 1 forward (~60 ms) and one host synchronisation per weight load.
+    MX_SELF_CHECK_TOL = 7.5e-4
+
+    def _mx_self_check(self, inp, clip_image, clip_mask) -> None:
+        if (not self.prec.mx or not self.mx_self_check or self.mx_self_check_result is not None or inp.shape[0] < 2 or
+                inp.shape[0] * self.g.grid * self.g.grid <= 4096 or torch.cuda.is_current_stream_capturing()):
+            return
+        self.mx_self_check_result = {"running": True}                  # (the forwards below come back through here)
+        m2, p2, l2 = (t.clone() for t in self.cascade(inp[:2], clip_image[:2], clip_mask[:2]))
+        m1, p1, l1 = self.cascade(inp[:1], clip_image[:1], clip_mask[:1])
+        dm, dl = float((m2[:1] - m1).abs().max()), float((l2[:1] - l1).abs().max())
+        same = bool(torch.equal(p2[:1], p1))
+        bad = not (dm <= self.MX_SELF_CHECK_TOL and dl <= self.MX_SELF_CHECK_TOL and same) or not math.isfinite(dm)
+        self.mx_self_check_result = {"max_abs_mask_diff": dm, "max_abs_class_logit_diff": dl, "pred_equal": same, "tolerance": self.MX_SELF_CHECK_TOL,
+                                     "demoted_to_exact": bad}
+        if bad:
+            import warnings
+            warnings.warn(f"camouflaged_vlm_amd: precision `mx` differs from `exact` on these weights by {dm:.2e} (mask logits) / {dl:.2e} (class "
+                          f"logits), prediction {'equal' if same else 'DIFFERENT'} on the first image (tolerance {self.MX_SELF_CHECK_TOL:.1e}): "
+                          "serving in precision `exact` from here on", RuntimeWarning)
+            exact = dataclasses.replace(self.prec, mx=False, qk=3, pv=3)
+            for eng in (self, self.encoder, self.decoder, self.clip):
+                eng.prec = exact
 
     # ---- LayerNorm-fold refusal guard ---------------------------------------------------------------------------
     # A row with |mu| / sigma > 128 cannot be served by the folded LayerNorm within the error budget:
@@ -1244,6 +1282,7 @@ class Cascade(_Base):
         return sparse
 
     def infer_test(self, inp, clip_image, clip_mask, taps: Optional[dict] = None) -> torch.Tensor:
+        self._mx_self_check(inp, clip_image, clip_mask)
         self.flush()
         self._fold_guard_check()
         g = self.g
@@ -1303,6 +1342,7 @@ class Cascade(_Base):
         feeding batches MUST call `flush()`; until then `pred` holds -1 and `logits` NaN (sentinels, never stale data).
         The inputs may be refilled in place as soon as the call has returned: `clip_image` / `clip_mask` are copied (on the
         caller's stream) into buffers the engine owns before anything reads them later."""
+        self._mx_self_check(inp, clip_image, clip_mask)
         if pipelined and self.fuse_clip:
             return self._cascade_fused(inp, clip_image, clip_mask)
         self.flush()

@@ -26,7 +26,7 @@ EXPORTS = [
     "cvlm_gemm_workspace_bytes", "cvlm_attention_workspace_bytes", "cvlm_row_stats_split", "cvlm_row_stats_split_mx", "cvlm_gather_rows_h2",
     "cvlm_ln_stats_merge", "cvlm_small_attention_h2", "cvlm_prob_quantise", "cvlm_prob_moments", "cvlm_prob_wfm",
 ]
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class GemmArgs(C.Structure):
@@ -52,6 +52,7 @@ class GemmArgs(C.Structure):
         ("a_mxs", C.c_void_p), ("lda_s", C.c_int64),
         ("w_mx", C.c_void_p), ("ldw_mx", C.c_int64), ("w_mxs", C.c_void_p), ("ldw_s", C.c_int64),
         ("out_mxs", C.c_void_p), ("ldo_s", C.c_int64), ("ldol", C.c_int64), ("ldrl", C.c_int64),
+        ("hm_nolo", C.c_int32),
     ]
 
 
@@ -305,7 +306,7 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
          ldoh: Optional[int] = None, alpha: float = 1.0, act: int = ACT_NONE, split: int = 3, batch: int = 1,
          stride_a: int = 0, stride_w: int = 0, stride_r: int = 0, stride_o: int = 0, stride_oh: int = 0,
          pixel_shuffle: Optional[Tuple[int, int, int]] = None,
-         head_major: Optional[Tuple[int, int, int]] = None, out_scale: float = 1.0,
+         head_major: Optional[Tuple[int, int, int]] = None, head_major_nolo: int = 0, out_scale: float = 1.0,
          workspace: Optional[torch.Tensor] = None,
          ln_fold: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          residual_h2: Optional[Tuple["H2", float]] = None, ldrh: Optional[int] = None,
@@ -326,6 +327,7 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     if getattr(a, "mx", False):
         assert w_mx is not None and w_mx.C >= K and a.C >= K, "an mx activation needs the mx image of the weight"
         g.a_hi, g.a_lo, g.lda, g.stride_a, g.a_mx = a.data_ptr(), 0, a.t.stride(0) // 2, 0, 1
+        assert a.s.stride(0) == 4 * a.s.stride(1), "an H2MX.every() view is a residual only: the kernels take the scale row stride as 4 * ld_s"
         g.a_mxs, g.lda_s = a.scale_ptr(), a.s.stride(1)
         g.w_mx, g.ldw_mx, g.w_mxs, g.ldw_s = w_mx.data_ptr(), w_mx.t.stride(0) // 2, w_mx.scale_ptr(), w_mx.s.stride(1)
     elif getattr(a, "il", False):
@@ -342,6 +344,7 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
     g.ldoh, g.stride_oh = (ldoh if ldoh is not None else N), stride_oh
     if out_h2 is not None and getattr(out_h2, "mx", False):
         g.out_hi, g.ldoh, g.out_mx = out_h2.data_ptr(), out_h2.t.stride(0) // 2, 1
+        assert out_h2.s.stride(0) == 4 * out_h2.s.stride(1), "an H2MX.every() view is a residual only: the kernels take the scale row stride as 4 * ld_s"
         g.out_mxs, g.ldo_s = out_h2.scale_ptr(), out_h2.s.stride(1)
         if out_h2.lo is not None:
             g.out_lo, g.ldol = out_h2.lo.data_ptr(), out_h2.lo.stride(0)
@@ -355,6 +358,7 @@ def gemm(a: H2, w: H2, M: int, N: int, K: int, *, lda: Optional[int] = None, ldw
         g.ps_h, g.ps_w, g.ps_c2 = pixel_shuffle
     if head_major is not None:
         g.hm_S, g.hm_H, g.hm_hd = head_major
+        g.hm_nolo = head_major_nolo                                # ABI 12: bit w set = the lo plane of q (0) / k (1) / v (2) is not written
     g.out_scale = out_scale
     if ln_fold is not None:
         assert tuple(ln_fold[0].shape) == (M, 2) and ln_fold[0].is_contiguous(), "ln_fold: merged statistics [M][2]"

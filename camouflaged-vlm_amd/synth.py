@@ -102,6 +102,8 @@ def make_full_state_dict(g: SamGeometry, c: ClipGeometry, seed: int = 0) -> Dict
         while len(_FULL_CACHE) >= 2:
             _FULL_CACHE.pop(next(iter(_FULL_CACHE)))
         _FULL_CACHE[key] = make_state_dict(full_entries(g, c), seed)
+        for arr in _FULL_CACHE[key].values():
+            arr.setflags(write=False)                    # shared with every later caller: an aliasing in-place write must fail, not poison them
     return dict(_FULL_CACHE[key])
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CVLM_ABI_VERSION 11
+#define CVLM_ABI_VERSION 12
 #define CVLM_E_BADARG (-1)
 #define CVLM_E_UNSUPPORTED (-2)
 #define CVLM_E_WORKSPACE (-3)     /* workspace missing or smaller than cvlm_*_workspace_bytes() */
@@ -132,6 +132,10 @@ typedef struct cvlm_gemm_args {
     const void* a_mxs; int64_t lda_s;
     const void* w_mx; int64_t ldw_mx; const void* w_mxs; int64_t ldw_s;
     void* out_mxs; int64_t ldo_s; int64_t ldol; int64_t ldrl;
+    /* ABI 12 -- head-major stores (hm_S > 0): bit w of hm_nolo (0 = q, 1 = k, 2 = v) set: the lo plane of that third of the columns is
+     * NOT written.  cvlm_attention with split_qk == 1 never reads K's lo plane: the qkv projection of a ViT-H block then leaves a sixth
+     * of its 503 MB of stores unwritten (hm_nolo = 2).  0: every plane is written, as before. */
+    int32_t hm_nolo;
 } cvlm_gemm_args;
 int cvlm_gemm(const cvlm_gemm_args* args, void* stream);
 int64_t cvlm_gemm_workspace_bytes(void);
@@ -221,10 +225,14 @@ int cvlm_reinterpret_transpose(const float* x, int32_t B, int32_t T, int32_t D, 
  *   1: hi planes only (lo pointers may be NULL); (3, 1) mixes them.  ABI 11 -- (2, 2): K and V keep their lo planes, Q and the
  *   probabilities P do not: q.k^T = q_hi.(k_hi + k_lo), P.v = fp16(P).(v_hi + v_lo) with P rounded to nearest and the softmax denominator
  *   summed from the rounded values (a ones-row product), so the quotient is an exact weighted mean of V rows with weights off by
- *   <= 2^-12 relative.  (Dropping the lo plane of K or V instead is NOT fp32-grade: profiles/r05_precision_sensitivity.log.)  The two
- *   ViT-H kernels (mode 1 on 64x64 / 96x96 maps, mode 2 with 14x14 windows) have this form; every other shape runs (2, 2) as (3, 3).
- *   All lo pointers are required, as for 3.
- * workspace: the split 3/3 and 2/2 global kernels for the 64x64 and 96x96 maps keep V transposed
+ *   <= 2^-12 relative.  ABI 12 -- (1, 2): K enters the scores as its hi plane too, q.k^T = q_hi.k_hi with ONE MFMA per k-step; K's lo
+ *   plane is neither fetched nor read (the rel-pos tables keep q_hi + q_lo against both table planes, P.v is that of (2, 2)).
+ *   Measured on the 16 reference images (profiles/r06_probe_kv_lo.log, profiles/r06_precision_emulate_attn.log): fp16(k) costs the masks
+ *   4e-5 -- less than fp16(q); fp16(v) costs 4e-4 and stays out.  (Round 5's probe builds said otherwise for K and V: their kernels
+ *   requested LDS fragments that no instruction consumed, and the allocator reused the registers while the reads were in flight.)
+ *   The two ViT-H kernels (mode 1 on 64x64 / 96x96 maps, mode 2 with 14x14 windows) have these forms; every other shape runs (2, 2) and
+ *   (1, 2) as (3, 3).  All lo pointers are required, as for 3.
+ * workspace: the split 3/3, 2/2 and 1/2 global kernels for the 64x64 and 96x96 maps keep V transposed
  * (cvlm_attention_workspace_bytes(args) bytes, 0 for every other mode); CVLM_E_WORKSPACE if it is missing there. */
 typedef struct cvlm_attn_args {
     const void* qkv_hi; const void* qkv_lo;

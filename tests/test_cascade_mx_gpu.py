@@ -15,8 +15,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-MX_MASK_TOL, MX_LOGIT_TOL, MX_IOU = 5e-4, 2.5e-4, 0.9999
-BATCH_TOL = 5e-4            # a batch (mx operands, split-2 attention) against a single-image forward (M = 4096: the `exact` arithmetic, engine.SamEncoder.attn_split)
+# MX_MASK_TOL: on the 4096 positions per image the bar was defined on in round 5; MX_MASK_TOL_ALL: on all 73728 positions a round-6 digest
+# holds per image (65536 more common ones + the image's 4096 smallest |logit|): the maximum over 18x as many samples sits 1.4-1.5x higher
+# (measured 5.0e-4 for the round-5 arithmetic and for this round's alike) -- twice inside the 1e-3 gate of BASELINE.json
+MX_MASK_TOL, MX_MASK_TOL_ALL, MX_LOGIT_TOL, MX_IOU = 5e-4, 6e-4, 2.5e-4, 0.9999
+BATCH_TOL = 7.5e-4          # a batch (mx operands, (1, 2) attention) against a single-image forward (M = 4096: the `exact` arithmetic, engine.SamEncoder.attn_split) over ALL mask logits: Cascade.MX_SELF_CHECK_TOL
 
 
 @pytest.fixture(scope="module")
@@ -39,7 +42,8 @@ def demo_mx(golden_dir):
 
 def gate(r):
     assert r["ok"], r
-    assert r["max_abs_mask_err"] <= MX_MASK_TOL and r["max_abs_class_logit_err"] <= MX_LOGIT_TOL and r["min_iou"] >= MX_IOU and r["pred_equal"], r
+    assert r["max_abs_mask_err_by_set"]["sparse"] <= MX_MASK_TOL and r["max_abs_mask_err"] <= MX_MASK_TOL_ALL, r
+    assert r["max_abs_class_logit_err"] <= MX_LOGIT_TOL and r["min_iou"] >= MX_IOU and r["pred_equal"], r
 
 
 def test_mx_mode_runs_the_mx_kernels(demo_mx):
@@ -71,7 +75,7 @@ def test_mx_mode_runs_the_mx_kernels(demo_mx):
         cas.cascade(inp[:1], ci[:1], cm[:1])
     finally:
         hip.gemm, hip.attention = orig, orig_attn
-    assert splits == {1: {(3, 3)}, 2: {(2, 2)}}, splits          # batches: two MFMAs per attention product; one image per call: the exact arithmetic
+    assert splits == {1: {(3, 3)}, 2: {(1, 2)}}, splits          # batches: one MFMA per k-step of q.k^T, two per step of P.v; one image per call: the exact arithmetic
     # per ViT-H block: qkv (but block 0's), lin1, lin2 read mx operands; proj, lin1, the prompt GEMM and lin2 (but the last) write them
     assert seen["a_mx"] >= 3 * g.depth - 1 and seen["out_mx"] >= 4 * g.depth - 2 and seen["res_mx"] >= 2 * g.depth - 1, seen
 
@@ -120,6 +124,144 @@ def test_mx_pipelined_loop_with_changing_batches(demo_mx):
         r = digest.check_cascade(m, p, l, dg, ids)
         assert r["checked_images"] == ids
         gate(r)
+
+
+def test_mx_self_check_passes_on_these_weights(demo_mx):
+    """Cascade._mx_self_check: the first batch of the module's engine ran the first two images as a batch (mx) and image 0 alone (exact)
+    and kept the mode: every mask logit of image 0 within MX_SELF_CHECK_TOL, same prediction."""
+    from camouflaged_vlm_amd import synth
+    cas, dg, g, c, dev = demo_mx
+    if cas.mx_self_check_result is None:
+        inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=2))
+        cas.cascade(inp, ci, cm)
+    r = cas.mx_self_check_result
+    print("mx self-check, synthetic weights seed 0:", r)
+    assert r is not None and not r["demoted_to_exact"] and r["pred_equal"] and r["max_abs_mask_diff"] <= cas.MX_SELF_CHECK_TOL and cas.prec.mx
+
+
+def test_mx_self_check_demotes_weights_that_leave_the_bar(golden_dir):
+    """... and weights built to trip it: the mask head's last hyper-network layer x 8 (mask logits of 8 x the range: every absolute error
+    of the cascade is 8 x larger -- `exact` stays inside the tolerance, `mx` does not).  The engine warns, serves the batch and everything
+    after it in `exact`: (3, 3) attention launches, no mx operands, and the batch equals its single-image forwards to the summation-order
+    tolerance."""
+    import warnings
+    from camouflaged_vlm_amd import hip, spec, synth
+    from camouflaged_vlm_amd.engine import Cascade, Precision
+    with np.load(os.path.join(golden_dir, "demo_digest.npz")) as z:
+        eot = z["eot_test"].tolist()
+    with np.load(os.path.join(golden_dir, "ovcamo_constants.npz")) as z:
+        bank = torch.from_numpy(z["bank_test"]).float()
+    g, c = spec.DEMO_SAM, spec.DEMO_CLIP
+    dev = torch.device("cuda:0")
+    sd_np = dict(synth.make_full_state_dict(g, c))
+    for k in ("mask_decoder.output_hypernetworks_mlps.0.layers.2.weight", "mask_decoder.output_hypernetworks_mlps.0.layers.2.bias"):
+        sd_np[k] = sd_np[k] * 8.0
+    cas = Cascade({k: torch.from_numpy(v) for k, v in sd_np.items()}, g, c, dev, Precision.named("mx"))
+    del sd_np
+    cas.clip.set_text_bank(cas.clip.text_features(eot, "test"), bank, "test")
+    inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=2))
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        m, p, l = (t.clone() for t in cas.cascade(inp, ci, cm))
+    r = cas.mx_self_check_result
+    print("mx self-check, mask head x 8:", r)
+    assert r["demoted_to_exact"] and r["max_abs_mask_diff"] > cas.MX_SELF_CHECK_TOL
+    assert any(issubclass(w.category, RuntimeWarning) and "serving in precision `exact`" in str(w.message) for w in caught)
+    assert not cas.prec.mx and not cas.encoder.prec.mx and not cas.clip.prec.mx and (cas.encoder.prec.qk, cas.encoder.prec.pv) == (3, 3)
+    seen = {"mx": 0, "splits": set()}
+    og, oa = hip.gemm, hip.attention
+
+    def spy_g(a, w, M, N, K, **kw):
+        seen["mx"] += bool(getattr(a, "mx", False)) + bool(getattr(kw.get("out_h2"), "mx", False))
+        return og(a, w, M, N, K, **kw)
+
+    def spy_a(qkv, o, Bn, S, heads, hd, **kw):
+        if kw.get("mode", 0) in (1, 2):
+            seen["splits"].add((kw.get("split_qk", 3), kw.get("split_pv", 3)))
+        return oa(qkv, o, Bn, S, heads, hd, **kw)
+    hip.gemm, hip.attention = spy_g, spy_a
+    try:
+        m2, p2, l2 = (t.clone() for t in cas.cascade(inp, ci, cm))
+    finally:
+        hip.gemm, hip.attention = og, oa
+    assert seen == {"mx": 0, "splits": {(3, 3)}}, seen
+    assert torch.equal(m2, m) and torch.equal(l2, l)                  # the batch that tripped the check was served in `exact` already
+    for b in range(2):
+        m1, p1, l1 = cas.cascade(inp[b:b + 1], ci[b:b + 1], cm[b:b + 1])
+        assert float((m1 - m[b:b + 1]).abs().max()) < 8 * 6e-5 and p1.cpu().tolist() == p[b:b + 1].cpu().tolist()
+    del cas
+    torch.cuda.empty_cache()
+
+
+def _cascade_for(dgname, golden_dir, seed=0, outliers=False):
+    from camouflaged_vlm_amd import spec, synth
+    from camouflaged_vlm_amd.engine import Cascade, Precision
+    with np.load(os.path.join(golden_dir, dgname)) as z:
+        dg = {k: z[k] for k in z.files}
+    with np.load(os.path.join(golden_dir, "ovcamo_constants.npz")) as z:
+        bank = torch.from_numpy(z["bank_test"]).float()
+    g, c = spec.DEMO_SAM, spec.DEMO_CLIP
+    dev = torch.device("cuda:0")
+    sd_np = synth.make_full_state_dict(g, c, seed)
+    if outliers:
+        sd_np = synth.apply_outliers(sd_np)
+    cas = Cascade({k: torch.from_numpy(v) for k, v in sd_np.items()}, g, c, dev, Precision.named("mx"))
+    del sd_np
+    cas.clip.set_text_bank(cas.clip.text_features(dg["eot_test"].tolist(), "test"), bank, "test")
+    return cas, dg, g, c, dev
+
+
+@pytest.mark.parametrize("dgname,seed,outliers", [("demo_digest_seed1.npz", 1, False), ("demo_digest_outliers.npz", 0, True)])
+def test_mx_other_weights_against_the_reference(golden_dir, dgname, seed, outliers):
+    """the mode's parity evidence on weights other than the one draw the 16-image digest uses -- the REFERENCE run at
+    the full demo geometry on synthetic weights of seed 1 (4 images) and on the outlier weights (synth.apply_outliers: massive residual
+    channels x 1e3 / x 1e4, a dead channel, hot MLP units; 2 images): one batch in precision `mx` (mx GEMM operands, split (1, 2)
+    attention), every image under the adoption bar, 73728 mask positions per image incl. its 4096 pixels nearest the decision."""
+    from camouflaged_vlm_amd import digest, synth
+    cas, dg, g, c, dev = _cascade_for(dgname, golden_dir, seed, outliers)
+    n = digest.n_images(dg)
+    assert n >= 2 and "dense_idx" in dg and bool(dg.get("outlier_weights", False)) == outliers and int(dg.get("weight_seed", 0)) == seed
+    inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=n))
+    m, p, l = cas.cascade(inp, ci, cm)
+    assert bool(torch.isfinite(m).all()) and bool(torch.isfinite(l).all())
+    r = digest.check_cascade(m, p, l, dg, list(range(n)))
+    print(f"mx, demo geometry, {dgname} ({n} images): {r}")
+    assert r["checked_images"] == list(range(n)) and r["mask_positions_per_image"] == 73728
+    gate(r)
+    for eng in (cas, cas.encoder, cas.decoder, cas.clip):
+        assert eng.ws.gemm_errors() == 0
+    del cas
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,value", [("CVLM_GEMM_TAIL", "0"), ("CVLM_GEMM_T192", "0"), ("ksplit", "False")])
+def test_mx_demo_geometry_under_the_launcher_switches(demo_mx, monkeypatch, name, value):
+    """the switches that steer the MX launcher (gemm.hip: K-parts of a partial last round, the 192-row tiles of the
+    CLIP h2-residual launches, no workspace at all) at their non-default values ON THE MX ENGINE, batch of 8 (the shapes bench.py times:
+    M = 32768 ViT-H launches, M = 9296 fused CLIP forward), every image against the reference under the adoption bar."""
+    from camouflaged_vlm_amd import digest, synth
+    cas, dg, g, c, dev = demo_mx
+    engines = (cas, cas.encoder, cas.decoder, cas.clip)
+    was = [e.ksplit for e in engines]
+    if name == "ksplit":
+        for e in engines:
+            e.ksplit = False
+    else:
+        monkeypatch.setenv(name, value)
+    try:
+        ids = list(range(8))
+        inp, ci, cm = (torch.from_numpy(t).to(dev) for t in synth.make_inputs(g, c, batch=8))
+        outs = [cas.cascade(inp, ci, cm, pipelined=True), cas.cascade(inp, ci, cm, pipelined=True)]   # the second call's stage 2 rides in the fused CLIP forward
+        cas.flush()
+        torch.cuda.synchronize()
+    finally:
+        for e, w in zip(engines, was):
+            e.ksplit = w
+    for m, p, l in outs:
+        r = digest.check_cascade(m, p, l, dg, ids)
+        assert r["checked_images"] == ids, (name, value, r)
+        gate(r)
+    assert sum(e.ws.gemm_errors() for e in engines) == 0
 
 
 def test_mx_outlier_weights_stay_with_the_split3_engine(golden_dir):

@@ -79,7 +79,9 @@ def to_dev_mx(m: "H.H2MX") -> "H.H2MX":
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K,form", [(4096, 1280, 96, "h2res"), (2056, 768, 160, "fold_gelu"), (4096, 64, 64, "plain_offset")])
+# (4096, 5120, 160): the shape the one-image column split takes (16 x 20 tiles of 256^2 -> one round + the rest as 128^2 tiles): an mx
+# image must not take it -- its groups and scale bytes do not move with a plain column offset
+@pytest.mark.parametrize("M,N,K,form", [(4096, 1280, 96, "h2res"), (2056, 768, 160, "fold_gelu"), (4096, 5120, 160, "fold_gelu"), (4096, 64, 64, "plain_offset")])
 def test_gemm_out_mx_is_mx_pack_of_the_planes(hip, M, N, K, form):
     """Producer side: image, exponents and lo plane of an out_mx launch == mx_pack of the planes the same launch writes as plain h2."""
     from camouflaged_vlm_amd.engine import Linear, LnLinear

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/cvlm.h but not exported"
     assert set(hip.EXPORTS) == declared
-    assert lib.cvlm_abi_version() == hip.ABI_VERSION == 11 and lib.cvlm_target_arch() == b"gfx950"
+    assert lib.cvlm_abi_version() == hip.ABI_VERSION == 12 and lib.cvlm_target_arch() == b"gfx950"
 
 
 def test_integration_doc_struct_matches_binding():
@@ -519,7 +519,7 @@ def test_precision_modes_and_what_one_image_per_call_runs():
     from camouflaged_vlm_amd.engine import Precision, SamEncoder
     from camouflaged_vlm_amd import host
     assert Precision.named("exact") == Precision(3, 3, 3, False)
-    assert Precision.named("mx") == Precision(3, 2, 2, True) and Precision.named("mx33") == Precision(3, 3, 3, True)
+    assert Precision.named("mx") == Precision(3, 1, 2, True) and Precision.named("mx22") == Precision(3, 2, 2, True) and Precision.named("mx33") == Precision(3, 3, 3, True)
     old = os.environ.pop("CVLM_PRECISION", None)
     try:
         assert host.precision_from_env() == Precision.named("mx")
@@ -530,5 +530,5 @@ def test_precision_modes_and_what_one_image_per_call_runs():
         if old is not None:
             os.environ["CVLM_PRECISION"] = old
     split = lambda name, M: SamEncoder.attn_split(types.SimpleNamespace(prec=Precision.named(name)), M)
-    assert split("mx", 4096) == (3, 3) and split("mx", 8192) == (2, 2) and split("mx", 32768) == (2, 2)
+    assert split("mx", 4096) == (3, 3) and split("mx", 8192) == (1, 2) and split("mx", 32768) == (1, 2)
     assert split("exact", 32768) == (3, 3) and split("mx33", 32768) == (3, 3) and split("fast", 4096) == (1, 1)

@@ -134,6 +134,8 @@ def test_digest_checker_accepts_the_reference_and_rejects_deviations(golden_dir)
         for i in ids:
             m = np.where(np.unpackbits(dg["mask_bits"][i])[:S * S].astype(bool), 1.0, -1.0).astype(np.float32)
             m[dg["sample_idx"]] = dg["mask_samples"][i]
+            m[dg["dense_idx"]] = dg["dense_samples"][i]              # round 6: 65536 common positions + the image's 4096 smallest |logit|
+            m[dg["near_idx"][i]] = dg["near_samples"][i]
             masks.append(m.reshape(1, S, S))
         return (torch.from_numpy(np.stack(masks)), torch.from_numpy(dg["pred"][ids].copy()),
                 torch.from_numpy(dg["class_logits"][ids].copy()))
@@ -141,6 +143,11 @@ def test_digest_checker_accepts_the_reference_and_rejects_deviations(golden_dir)
     m, p, l = outputs()
     r = digest.check_cascade(m, p, l, dg, ids)
     assert r["ok"] and r["checked_images"] == ids and r["min_iou"] == 1.0 and r["max_abs_mask_err"] == 0.0
+    assert r["mask_positions_per_image"] == 4096 + 65536 + 4096 and set(r["max_abs_mask_err_by_set"]) == {"sparse", "dense", "near"}
+    m3 = m.clone()
+    m3.view(3, -1)[0, int(dg["near_idx"][0][7])] += 2e-3              # one pixel next to the decision boundary off by 2e-3: only the near set sees it
+    r3 = digest.check_cascade(m3, p, l, dg, ids)
+    assert not r3["ok"] and r3["max_abs_mask_err_by_set"]["near"] > 1e-3
     m2 = m.clone()
     m2[1, 0, :64, :64] *= -1.0                                       # flip a 64 x 64 patch of image 5
     assert not digest.check_cascade(m2, p, l, dg, ids)["ok"]

@@ -214,19 +214,33 @@ def tokens(out_dir, mods):
     print("tokens:", tk_train.shape, tk_test.shape, "eot test", tk_test.argmax(-1)[:8])
 
 
-def demo_digest(out_dir, mods, n_images=16, check=False):
+N_DENSE, N_NEAR = 65536, 4096        # round 6: mask logits kept per image -- a dense common sample and each image's pixels nearest the decision
+
+
+def demo_digest(out_dir, mods, n_images=16, check=False, seed=0, outliers=False, name="demo_digest.npz"):
     """G3: full demo.yaml geometry, B=1 per image (the reference is B=1 only), digests only.  Every array is PER IMAGE
     (leading dimension n_images): packed mask bits, 4096 sampled mask logits (the same positions for every image),
     class logits of both CLIP passes, predictions.  Images are `synth.make_inputs(..., batch=n)` rows 0..n-1, i.e. image i
     does not depend on n: a run with fewer images reproduces a prefix of the committed file (--check compares that prefix).
-    bench.py times batches of 8 (images 0-7 and 8-15 alternate; rank 1 of a multi-GPU run owns 8-15)."""
+    bench.py times batches of 8 (images 0-7 and 8-15 alternate; rank 1 of a multi-GPU run owns 8-15).
+
+    Round 6: beside the 4096 positions of rounds 1-5 every image also keeps N_DENSE = 65536 common positions
+    (`dense_idx` / `dense_samples`: 6 % of the pixels) and ITS OWN N_NEAR = 4096 positions of smallest |logit| (`near_idx` /
+    `near_samples`: where a sign can flip); `seed` draws other synthetic weights (`demo_digest_seed1.npz`), `outliers` applies
+    `synth.apply_outliers` to them (`demo_digest_outliers.npz`: massive residual channels, a hot MLP unit) -- the mx arithmetic's
+    parity evidence no longer rests on one weight draw."""
     mm, ml, cm, train_names, test_names = mods
     g, c = spec.DEMO_SAM, spec.DEMO_CLIP
-    model, sd, eot_train, eot_test = build_reference(mm, ml, cm, g, c, train_names, test_names)
+    model, sd, eot_train, eot_test = build_reference(mm, ml, cm, g, c, train_names, test_names, seed=seed)
+    if outliers:
+        sd = outlier_weights(sd)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     inp, clip_image, clip_mask = synth.make_inputs(g, c, batch=n_images)
     import time
     rng = np.random.default_rng(0)
     idx = rng.integers(0, inp.shape[2] * inp.shape[3], size=4096)
+    dense_idx = np.random.default_rng(6).choice(inp.shape[2] * inp.shape[3], size=N_DENSE, replace=False).astype(np.int32)
+    dense, near_i, near_v = [], [], []
     bits, samples, stats, preds, logits, logits1, secs = [], [], [], [], [], [], []
     # encoder output (B,256,64,64) of the same run: the `--workload encoder` bench line (BASELINE configs[1]) is checked
     # against these samples / channel means; the first infer_test call of run_reference is the one recorded
@@ -242,16 +256,23 @@ def demo_digest(out_dir, mods, n_images=16, check=False):
         fsamples.append(feats[0].reshape(-1)[feat_idx].astype(np.float32))
         fcmean.append(feats[0].mean(axis=(0, 2, 3)).astype(np.float32))
         bits.append(np.packbits(m > 0)); samples.append(m.reshape(-1)[idx])
+        flat = m.reshape(-1)
+        dense.append(flat[dense_idx])
+        ni = np.sort(np.argpartition(np.abs(flat), N_NEAR)[:N_NEAR]).astype(np.int32)
+        near_i.append(ni); near_v.append(flat[ni])
         stats.append([m.mean(), m.std(), m.min(), m.max()])
         preds.append(p[0]); logits.append(s[0]); logits1.append(s1[0])
-        print("demo: image %d in %.1f s; mask std %.3f; pred %s" % (b, secs[-1], m.std(), p), flush=True)
+        print("demo: image %d in %.1f s; mask std %.3f; pred %s; largest |logit| of the near set %.3e" % (b, secs[-1], m.std(), p, np.abs(flat[ni]).max()), flush=True)
     out = dict(mask_bits=np.stack(bits), mask_samples=np.stack(samples).astype(np.float32), sample_idx=idx,
                mask_stats=np.array(stats, np.float64), pred=np.array(preds, np.int64),
                class_logits=np.stack(logits).astype(np.float32), pass1_logits=np.stack(logits1).astype(np.float32),
                eot_test=eot_test, eot_train=eot_train, feat_idx=feat_idx, feat_samples=np.stack(fsamples),
-               feat_channel_mean=np.stack(fcmean))
+               feat_channel_mean=np.stack(fcmean), dense_idx=dense_idx, dense_samples=np.stack(dense).astype(np.float32),
+               near_idx=np.stack(near_i), near_samples=np.stack(near_v).astype(np.float32))
+    if seed or outliers:
+        out.update(weight_seed=np.int64(seed), outlier_weights=np.bool_(outliers))
     hook.remove()
-    path = os.path.join(out_dir, "demo_digest.npz")
+    path = os.path.join(out_dir, name)
     if check:
         _check_prefix(path, out, n_images)
         return
@@ -510,6 +531,8 @@ if __name__ == "__main__":
     ap.add_argument("--skip-tiny", action="store_true")
     ap.add_argument("--only-demo-digest", action="store_true")
     ap.add_argument("--only-demo-alpha-digest", action="store_true")
+    ap.add_argument("--only-demo-seed1-digest", action="store_true", help="demo geometry, weight seed 1 (default 4 images) -> demo_digest_seed1.npz")
+    ap.add_argument("--only-demo-outlier-digest", action="store_true", help="demo geometry, synth.apply_outliers weights (default 2 images) -> demo_digest_outliers.npz")
     ap.add_argument("--only-tiny", action="store_true")
     ap.add_argument("--only-train-branch", action="store_true")
     ap.add_argument("--images", type=int, default=None,
@@ -534,6 +557,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if args.only_demo_digest:
         demo_digest(args.out, mods, args.images or 16, args.check)
+        sys.exit(0)
+    if args.only_demo_seed1_digest:
+        demo_digest(args.out, mods, args.images or 4, args.check, seed=1, name="demo_digest_seed1.npz")
+        sys.exit(0)
+    if args.only_demo_outlier_digest:
+        demo_digest(args.out, mods, args.images or 2, args.check, outliers=True, name="demo_digest_outliers.npz")
         sys.exit(0)
     if args.only_demo_alpha_digest:
         demo_alpha_digest(args.out, mods, args.images or 1, args.check)

@@ -70,7 +70,10 @@ def main():
             r = digest.check_cascade(m, p, l, dg, ids)
             worst["mask"] = max(worst["mask"], r["max_abs_mask_err"]); worst["logit"] = max(worst["logit"], r["max_abs_class_logit_err"])
             worst["iou"] = min(worst["iou"], r["min_iou"]); worst["pred"] = worst["pred"] and r["pred_equal"]
-        print("  %-8s %12.3e %12.3e %10.6f %6s" % (mode, worst["mask"], worst["logit"], worst["iou"], "same" if worst["pred"] else "DIFF"), flush=True)
+            for kk, vv in r["max_abs_mask_err_by_set"].items():
+                worst["set_" + kk] = max(worst.get("set_" + kk, 0.0), vv)
+        print("  %-8s %12.3e %12.3e %10.6f %6s   %s" % (mode, worst["mask"], worst["logit"], worst["iou"], "same" if worst["pred"] else "DIFF",
+                                                     " ".join("%s %.3e" % (kk[4:], vv) for kk, vv in worst.items() if kk.startswith("set_"))), flush=True)
     hip.attention = orig
 
 
