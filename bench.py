@@ -54,7 +54,7 @@ ENCODER_TFLOP_PER_IMAGE = {1024: 5.681, 1536: 13.712}
 # Measured on this part (tools/power_roofline.py, profiles/r02_power_roofline.log): an MFMA-only loop (16x16x32 f16, random
 # operands, every CU) settles at 1.88 PF at the 1400-W socket cap (sclk 1.95 GHz of 2.4): what the matrix pipe can sustain.
 MFMA_F16_POWER_ROOFLINE_TFLOPS = 1880.0
-TRAFFIC_FILES = {"mx": ("r05_gemm_traffic.json",), "exact": ("r05_gemm_traffic_exact.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")}   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest first
+TRAFFIC_FILES = {"mx": ("r06_gemm_traffic.json", "r05_gemm_traffic.json"), "exact": ("r05_gemm_traffic_exact.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json")}   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, newest first
 
 
 def under_profiler() -> bool:
@@ -935,6 +935,7 @@ def main():
                            "pred_equal": all(r["pred_equal"] for r in res), "tolerance": digest.TOL,
                            "ok": bool(finite and all(r["ok"] for r in res))})
         cas = model.cascade()
+        parity["mx_self_check"] = cas.mx_self_check_result
         parity["gemm_handoff_errors"] = sum(e.ws.gemm_errors() for e in (cas, cas.encoder, cas.decoder, cas.clip))
         parity["ok"] = bool(parity["ok"] and parity["gemm_handoff_errors"] == 0)
         roofline = None
@@ -999,6 +1000,10 @@ def main():
                       "max_abs_diff_rank0": float(max((alone - tf).abs().max(), (alone_tr - tf_tr).abs().max()))}
     cas.clip.set_text_bank(tf, bank, "test")
     cas.clip.set_text_bank(tf_tr, torch.from_numpy(host.ovcamo_constants()["bank_train"][:c.n_cls_train]).float(), "train")
+    # precision mx: the engine's self-check on these weights (two images as a batch against image 0 alone in `exact`) runs here, in the setup,
+    # not inside the warm-up or the timed region
+    cas._mx_self_check(*batches[0])
+    torch.cuda.synchronize()
     setup_s = time.time() - t0
 
     def step(k):
@@ -1029,6 +1034,7 @@ def main():
                            "pred_equal": all(r["pred_equal"] for r in res), "tolerance": digest.TOL,
                            "ok": bool(finite and all(r["ok"] for r in res))})
     # split-K hand-offs a tail workgroup gave up on (the tile is NaN then, caught above too): 0 in a healthy run
+    parity["mx_self_check"] = cas.mx_self_check_result
     parity["gemm_handoff_errors"] = sum(e.ws.gemm_errors() for e in (cas, cas.encoder, cas.decoder, cas.clip))
     parity["ok"] = bool(parity["ok"] and parity["gemm_handoff_errors"] == 0)
     if n_dig and os.path.exists(dpath) and not parity["parity_checked"]:

@@ -452,6 +452,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         static_assert(BN == 256 && PER_WAVE * NWAVE == (BM + BN) / 8, "one staging instruction per 8 rows");
         constexpr int PW_A = BM / 8 / NWAVE, PW_W = BN / 8 / NWAVE;        // pieces per wave and unit: activation rows, weight rows
         constexpr bool DMA_ONLY = DBG == 2 || (DBG >= 12 && DBG <= 18);
+        // probes 20-22 (round 6, tools/probe_gemm_mx.py): what a 3-byte operand (fp16 hi + lo8; hi8 formed in registers) would cost and buy, BEFORE
+        // building it -- timing only, wrong numbers.  HALF_E4: the e4m3 units fetch half their lines (the stream of a 3-byte operand).
+        // CONVERT: the e4m3 units build their operands the way that kernel would: the fp16 lines of the unit before (two ds_read_b128 per
+        // fragment), eight v_cvt_scalef32_pk_fp8_f16 + the scale's extraction per fragment, and ONE ds_read_b128 of lo8 bytes.
+        constexpr bool HALF_E4 = DBG == 20 || DBG == 21, CONVERT = DBG == 21 || DBG == 22;
         // probes 16-19 (tools/probe_gemm_mx.py): where do the operand stream's lines come from?  16 / 19: the activation rows of every tile wrapped
         // into rows 0..255 (always L2-resident; 19: in the full kernel -- wrong numbers, right timing), 17: into rows 0..8191 (infinity-cache
         // resident), 18: activation and weight rows both wrapped into 0..255
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
         auto dma_piece = [&](int j, int u) {
             const bool isW = j < PW_W;
             const int blk = isW ? wave * PW_W + j : wave * PW_A + (j - PW_W);
+            if (HALF_E4 && (u & 1) && (j & 1)) return;               // probe: an e4m3 unit's lines are 64 bytes per row
             int row = (isW ? bn : bm) + blk * 8;
             const int lim = (isW ? g.N : g.M) - 8;
             row = row < lim ? row : lim;
@@ -581,12 +587,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 }
             }
         };
+        // probe CONVERT: fragment i of an e4m3 unit u from the fp16 lines of unit u - 1 (16 values of this lane -> 16 e4m3 bytes) + 16 lo8 bytes of unit u
+        auto conv_frag = [&](const unsigned char* b16, const unsigned char* b8, int off0, int off1, int word, int sel, bool wside) -> intx8 {
+            typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+            typedef short s2v __attribute__((ext_vector_type(2)));
+            const half8 h0 = *(const half8*)(b16 + off0), h1 = *(const half8*)(b16 + off1);
+            const intx4 lo = *(const intx4*)(b8 + off0);
+            const float sc = __builtin_bit_cast(float, (int)(__builtin_amdgcn_ubfe((unsigned)word, 8u * (unsigned)sel, 8u) << 23));
+            s2v c[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const half8 h = q ? h1 : h0;
+                c[2 * q] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c[2 * q], h2v{h[0], h[1]}, sc, false);
+                c[2 * q] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c[2 * q], h2v{h[2], h[3]}, sc, true);
+                c[2 * q + 1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c[2 * q + 1], h2v{h[4], h[5]}, sc, false);
+                c[2 * q + 1] = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(c[2 * q + 1], h2v{h[6], h[7]}, sc, true);
+            }
+            const intx4 hi8 = intx4{__builtin_bit_cast(int, c[0]), __builtin_bit_cast(int, c[1]), __builtin_bit_cast(int, c[2]), __builtin_bit_cast(int, c[3])};
+            return wside ? __builtin_shufflevector(hi8, lo, 0, 1, 2, 3, 4, 5, 6, 7) : __builtin_shufflevector(lo, hi8, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto conv_w = [&](int u, int sel) {
+            const unsigned char* b8 = smem + ((2 * u + 1) % NHS) * HALF_SLOT;
+            const unsigned char* b16 = smem + ((2 * u + 4) % NHS) * HALF_SLOT;       // W(u - 1): (2 (u - 1) + 1) % 5
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = conv_frag(b16 + i * 2048, b8 + i * 2048, fw0, fw1, sw[i], sel, true);
+        };
+        auto conv_a = [&](int u, int mh, int sel) {
+            const unsigned char* b8 = smem + ((2 * u) % NHS) * HALF_SLOT;
+            const unsigned char* b16 = smem + ((2 * u + 3) % NHS) * HALF_SLOT;       // A(u - 1): (2 (u - 1)) % 5
+#pragma unroll
+            for (int i = 0; i < MH; ++i) af[i] = conv_frag(b16 + (mh * MH + i) * 2048, b8 + (mh * MH + i) * 2048, fa0, fa1, sa[mh * MH + i], sel, false);
+        };
         auto kind_of = [](auto r_c) { constexpr int R = decltype(r_c)::value; return std::integral_constant<int, (R & 1) ? 1 + (R >> 1) : 0>{}; };
         auto frag_p0 = [&](int t) { if (!DMA_ONLY && DBG != 9) { read_w(t); read_a(t, 0); } };
         auto frag_p1 = [&](int t) { if (!DMA_ONLY && DBG != 9) read_a(t, 1); };
         // everything but the youngest batch's activation pieces (and, where said, the scale loads behind them) has landed
         auto wait_landed = [&](int t, bool scales_behind) {
-            if (t + 2 < nk && !(DBG == 1 && t > 1)) { if (scales_behind) wait_vmcnt<PW_A + 4 + MT>(); else wait_vmcnt<PW_A>(); }
+            if (t + 2 < nk && !(DBG == 1 && t > 1)) {
+                if (HALF_E4 && (t & 1)) { if (scales_behind) wait_vmcnt<PW_A / 2 + 4 + MT>(); else wait_vmcnt<PW_A / 2>(); }   // the youngest batch carries A(t + 2): half its pieces
+                else if (scales_behind) wait_vmcnt<PW_A + 4 + MT>(); else wait_vmcnt<PW_A>();
+            }
             else wait_vmcnt<0>();
         };
         // ---- prologue: A(0), W(0), A(1) (the batches "-3" and "-2" of the steady state); unit 0 landed behind the barrier
@@ -618,9 +658,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_nt_kernel(const GemmPara
                 if (t + 2 < nk) wait_vmcnt<PER_WAVE>(); else wait_vmcnt<0>();
                 touch_scales();
             }
-            frag_p0(t);
+            if constexpr (CONVERT && (R & 1)) { conv_w(t, R >> 1); conv_a(t, 0, R >> 1); } else frag_p0(t);
             mfma_half(kind_of(r_c), 0, t - 1, !grpB || t == 0);
-            frag_p1(t);
+            if constexpr (CONVERT && (R & 1)) conv_a(t, 1, R >> 1); else frag_p1(t);
             if (grpB) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every fragment of unit t is in registers: its half-slots may go
                 if (R == 0 && t != 0) wait_landed(t, true); else wait_landed(t, false);

@@ -39,6 +39,9 @@ int cvlm_gemm_k::launch_mx(GemmParams& p, int mt, int epi, int extra_blocks, int
             case 17: return launch_one<8, 1, 17>(p, extra_blocks, s);
             case 18: return launch_one<8, 1, 18>(p, extra_blocks, s);
             case 19: return launch_one<8, 1, 19>(p, extra_blocks, s);
+            case 20: return launch_one<8, 1, 20>(p, extra_blocks, s);
+            case 21: return launch_one<8, 1, 21>(p, extra_blocks, s);
+            case 22: return launch_one<8, 1, 22>(p, extra_blocks, s);
             default: break;
         }
     }
@@ -52,6 +55,9 @@ int cvlm_gemm_k::launch_mx(GemmParams& p, int mt, int epi, int extra_blocks, int
             case 17: return launch_one<8, 2, 17>(p, extra_blocks, s);
             case 18: return launch_one<8, 2, 18>(p, extra_blocks, s);
             case 19: return launch_one<8, 2, 19>(p, extra_blocks, s);
+            case 20: return launch_one<8, 2, 20>(p, extra_blocks, s);
+            case 21: return launch_one<8, 2, 21>(p, extra_blocks, s);
+            case 22: return launch_one<8, 2, 22>(p, extra_blocks, s);
             default: break;
         }
     }

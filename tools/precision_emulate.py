@@ -103,9 +103,10 @@ def contract(x, w, mode):
         return xh @ wh.t() + xl @ wh.t()
     if mode == "two_w":
         return xh @ wh.t() + xh @ wl.t()
-    if mode == "mx":
-        _, xh8, xl8 = mx_planes(x)
-        _, wh8, wl8 = mx_planes(w)
+    if mode in ("mx", "mx64"):                           # mx64: ONE exponent per 64 k-elements (round 6 study: what a shared exponent would cost)
+        blk = 32 if mode == "mx" else 64
+        _, xh8, xl8 = mx_planes(x, blk)
+        _, wh8, wl8 = mx_planes(w, blk)
         return xh @ wh.t() + xl8 @ wh8.t() + xh8 @ wl8.t()
     if mode.startswith("mix"):                           # mix<a>_<b>: xl.wh in format a, xh.wl in format b
         a, b = mode[3:].split("_")
@@ -144,7 +145,10 @@ _SD = {}
 def run(mode, gold, n_img=2, families=None, demo_image=None):
     g, c = (spec.TINY_SAM, spec.TINY_CLIP) if demo_image is None else (spec.DEMO_SAM, spec.DEMO_CLIP)
     if g not in _SD:
-        _SD[g] = O.to_torch_sd(synth.make_full_state_dict(g, c))
+        np_sd = synth.make_full_state_dict(g, c)
+        if os.environ.get("EMULATE_OUTLIERS") == "1":      # synth.apply_outliers weights: compare with tests/golden/demo_digest_outliers.npz
+            np_sd = synth.apply_outliers(np_sd)
+        _SD[g] = O.to_torch_sd(np_sd)
     sd = _SD[g]
     if demo_image is None:
         inp, ci, cm = (torch.from_numpy(t) for t in synth.make_inputs(g, c, n_img))
@@ -206,7 +210,7 @@ def main():
 def demo(args):
     import time
     from camouflaged_vlm_amd import digest
-    dg = digest.load(digest.golden_path("demo_digest.npz"))
+    dg = digest.load(digest.golden_path("demo_digest_outliers.npz" if os.environ.get("EMULATE_OUTLIERS") == "1" else "demo_digest.npz"))
     consts = {"bank_test": dg["bank_test"] if "bank_test" in dg else None, "eot_test": dg["eot_test"]}
     if consts["bank_test"] is None:
         with np.load(os.path.join(ROOT, "tests", "golden", "ovcamo_constants.npz")) as z:

@@ -31,7 +31,7 @@ else:
         kw.update(head_major=(4096, 16, 80))
         out = H.H2.empty(M, N, device=dev)
 if SHAPE == "lin2":
-    PROBES = {"101", "102", "103", "106", "116", "117", "118", "119"}
+    PROBES = {"101", "102", "103", "106", "116", "117", "118", "119", "120", "121", "122"}
 forms = [("split-3 kernel", None, "0"), ("mx kernel", 1, "0"), ("mx, no DMA in the steady state", 1, "101"), ("mx, DMA only (no reads, no MFMAs)", 1, "102"),
          ("mx, no fragment reads", 1, "109"), ("mx, only the f16 units multiply", 1, "110"), ("mx, only the fp8 units multiply", 1, "111"),
          ("mx, main loop only (no epilogue)", 1, "106"), ("mx, epilogue without its global stores", 1, "103"),
@@ -41,7 +41,12 @@ forms = [("split-3 kernel", None, "0"), ("mx kernel", 1, "0"), ("mx, no DMA in t
          ("mx, DMA only, activation rows wrapped into rows 0..255 (L2-resident)", 1, "116"),
          ("mx, DMA only, activation rows wrapped into rows 0..8191 (infinity-cache resident)", 1, "117"),
          ("mx, DMA only, activation AND weight rows wrapped into rows 0..255", 1, "118"),
-         ("mx kernel, activation rows wrapped into rows 0..255 (timing only)", 1, "119")]
+         ("mx kernel, activation rows wrapped into rows 0..255 (timing only)", 1, "119"),
+         ("3-byte operand, stream only: e4m3 units fetch half their lines (timing only)", 1, "120"),
+         ("3-byte operand: half lines + hi8 formed in registers (timing only)", 1, "121"),
+         ("hi8 formed in registers, full 4-byte stream (timing only)", 1, "122")]
+if os.environ.get("ONLY3"):
+    forms = [f for f in forms if f[2] in ("0", "102", "120", "121", "122")]
 if SHAPE == "lin2":
     forms = [f for f in forms if f[2] == "0" or f[2] in PROBES]
 res = {f[0]: [] for f in forms}
