@@ -67,8 +67,11 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap = argparse.ArgumentParser(prog="python -m camouflaged_vlm_amd.run", description=__doc__,
                                  formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--device", type=int, default=None, help="GPU index to run on (see above)")
-    ap.add_argument("--precision", choices=["exact", "mx", "mx33", "mixed", "fast"], default=None,
-                    help="sets CVLM_PRECISION for the drop-in modules (default exact: the parity mode)")
+    ap.add_argument("--precision", choices=["exact", "mx", "mx22", "mx33", "mixed", "fast"], default=None,
+                    help="sets CVLM_PRECISION for the drop-in modules.  Default mx: e4m3 correction products in the large GEMMs, one-term q.k^T / "
+                         "two-term P.v in the ViT-H attention on batches of two or more images (mask logits within 5.0e-4 of the reference on 16 "
+                         "images x 73728 positions; one image per call runs `exact`, and the first batch on a set of weights is checked against "
+                         "`exact` by the engine).  exact: three f16 products per multiply everywhere (5e-5 of the reference, ~10 %% slower on batches)")
     ap.add_argument("script", help="the reference script to run, e.g. demo.py")
     ap.add_argument("args", nargs=argparse.REMAINDER, help="arguments of the script")
     ns = ap.parse_args(argv)
