@@ -330,6 +330,8 @@ class Roofline:
             nb = kw.get("batch", 1)
             by = 4.0 * (M * K + N * K) * nb + (4.0 * M * N * nb if (kw.get("residual") is not None or kw.get("residual_h2") is not None) else 0.0) \
                 + 4.0 * M * N * nb * ((kw.get("out_f32") is not None) + (kw.get("out_h2") is not None))
+            if kw.get("head_major_nolo"):                      # ABI 12: a third's lo plane is not written (2 B per element of that third)
+                by -= 2.0 * M * (N // 3) * bin(int(kw["head_major_nolo"]) & 7).count("1")
             records.append((2.0 * M * N * K * nb, e0, e1, by, bool(getattr(a, "mx", False))))
 
         def timed_attn(qkv, o, Bn, S, heads, hd, **kw):
