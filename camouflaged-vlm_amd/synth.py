@@ -104,6 +104,9 @@ def make_full_state_dict(g: SamGeometry, c: ClipGeometry, seed: int = 0) -> Dict
         _FULL_CACHE[key] = make_state_dict(full_entries(g, c), seed)
         for arr in _FULL_CACHE[key].values():
             arr.setflags(write=False)                    # shared with every later caller: an aliasing in-place write must fail, not poison them
+        # torch.from_numpy on a read-only array warns once per process that writes through the tensor are undefined: exactly the protection wanted
+        import warnings
+        warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
     return dict(_FULL_CACHE[key])
 
 
