@@ -612,6 +612,30 @@ def test_gemm_head_major_store(hip):
     assert torch.equal(o1.t[1].cpu(), to_head_major(o0.t[1].cpu(), Bn, S, Hh, hd))
 
 
+@pytest.mark.parametrize("S,hd,nolo", [(256, 80, 2), (256, 80, 5), (200, 80, 2), (50, 20, 2)])
+def test_gemm_head_major_store_without_a_lo_plane(hip, S, hd, nolo):
+    """cvlm_gemm_args.hm_nolo (ABI 12): bit w set = the lo plane of third w (q / k / v) of a head-major store is NOT written -- the attention
+    kernels' split (1, 2) never reads K's.  Everything else is the bits of the plain head-major store; the skipped thirds keep what was
+    there.  (256, 80): the LDS-staged epilogue; (200, 80) and (50, 20): the direct store of the accumulator layout (S below a wave's rows /
+    head dim not a multiple of 8)."""
+    Bn, Hh, K = 2, 2, 64
+    M, N = Bn * S, 3 * Hh * hd
+    a, w, bias = rnd(M, K, seed=53), rnd(N, K, seed=54, scale=0.1), rnd(N, seed=55)
+    A, W = dev_h2(hip, a), dev_h2(hip, w)
+    full, part = hip.H2.empty(M, N), hip.H2.empty(M, N)
+    part.t.fill_(7.0)
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=full, head_major=(S, Hh, hd))
+    hip.gemm(A, W, M, N, K, bias=bias.cuda(), out_h2=part, head_major=(S, Hh, hd), head_major_nolo=nolo)
+    torch.cuda.synchronize()
+    assert torch.equal(part.t[0], full.t[0])                            # hi planes: all three thirds
+    lo_f, lo_p = full.t[1].reshape(3, -1), part.t[1].reshape(3, -1)     # head-major: the thirds are contiguous
+    for which in range(3):
+        if (nolo >> which) & 1:
+            assert bool((lo_p[which] == 7.0).all()), which
+        else:
+            assert torch.equal(lo_p[which], lo_f[which]), which
+
+
 def test_layernorm(hip):
     for M, D, eps in [(37, 1280, 1e-6), (10, 160, 1e-6), (5, 64, 1e-6), (300, 1024, 1e-5)]:
         x, add = rnd(M, D, seed=13) * 3 + 1, rnd(7, D, seed=14)
