@@ -217,7 +217,11 @@ print("rank", rank, "ok")
 def test_text_bank_sharding_over_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
-    env = dict(os.environ, CVLM_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2")
+    import socket
+    with socket.socket() as sk:                                        # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CVLM_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
